@@ -1,0 +1,234 @@
+"""ctypes binding of include/hpf.h (libhpf_hip.so).
+
+This is the reference-side binding a Python caller would use; the C++ host
+(`hgaprec` CLI, hgaprec_amd/csrc/host/) links the same library directly.
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, loading / `Hpf(...)` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libhpf_hip.so"
+
+HPF_OK = 0
+STATE_NAMES = [
+    "THETA_SHAPE", "THETA_RATE", "THETA_E", "THETA_ELOG",
+    "BETA_SHAPE", "BETA_RATE", "BETA_E", "BETA_ELOG",
+    "XI_SHAPE", "XI_RATE", "XI_E", "XI_ELOG",
+    "ETA_SHAPE", "ETA_RATE", "ETA_E", "ETA_ELOG",
+    "UBIAS_SHAPE", "UBIAS_RATE", "UBIAS_E", "UBIAS_ELOG",
+    "IBIAS_SHAPE", "IBIAS_RATE", "IBIAS_E", "IBIAS_ELOG",
+]
+STATE = {n: i for i, n in enumerate(STATE_NAMES)}
+
+# every symbol include/hpf.h declares (tests check the library exports them all)
+EXPORTS = [
+    "hpf_abi_version", "hpf_strerror", "hpf_last_error", "hpf_create", "hpf_destroy",
+    "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
+    "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
+    "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
+    "hpf_algorithmic_bytes",
+]
+
+
+class HpfConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_users", C.c_uint32), ("n_items", C.c_uint32),
+        ("K", C.c_uint32), ("hier", C.c_uint32), ("bias", C.c_uint32),
+        ("binary", C.c_uint32), ("n_users_total", C.c_uint32), ("device", C.c_int32),
+        ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("reserved0", C.c_uint32),
+        ("stream", C.c_void_p), ("s_prior", C.c_double), ("r_prior", C.c_double),
+    ]
+
+
+class HpfTiming(C.Structure):
+    _fields_ = [
+        ("phi_user_ms", C.c_float), ("phi_item_ms", C.c_float),
+        ("sweep_user_ms", C.c_float), ("sweep_item_ms", C.c_float),
+        ("iteration_ms", C.c_float), ("iterations", C.c_uint32),
+    ]
+
+
+class HpfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen libhpf_hip.so and declare the prototypes.  Fails loudly."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise HpfError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(p))
+    vp, u32p, dp = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    lib.hpf_abi_version.restype = C.c_int
+    lib.hpf_strerror.restype = C.c_char_p
+    lib.hpf_strerror.argtypes = [C.c_int]
+    lib.hpf_last_error.restype = C.c_char_p
+    lib.hpf_last_error.argtypes = [vp]
+    lib.hpf_create.argtypes = [C.POINTER(HpfConfig), C.POINTER(vp)]
+    lib.hpf_destroy.argtypes = [vp]
+    lib.hpf_destroy.restype = None
+    lib.hpf_upload_csr.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
+    lib.hpf_set_state.argtypes = [vp, C.c_int, dp, C.c_size_t]
+    lib.hpf_get_state.argtypes = [vp, C.c_int, dp, C.c_size_t]
+    lib.hpf_iterate.argtypes = [vp, C.c_int]
+    lib.hpf_iterate_local.argtypes = [vp]
+    lib.hpf_iterate_global.argtypes = [vp]
+    lib.hpf_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.hpf_bind_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
+    lib.hpf_heldout_ll.argtypes = [vp, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t, dp,
+                                   C.POINTER(C.c_uint64)]
+    lib.hpf_synchronize.argtypes = [vp]
+    lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
+    lib.hpf_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Hpf:
+    """One device-side model (one rank's shard).  Thin, 1:1 over the C-ABI."""
+
+    def __init__(self, n_users, n_items, K, hier=True, bias=False, binary=False,
+                 device=0, stream=None, n_ranks=1, rank=0, n_users_total=0,
+                 s_prior=0.3, r_prior=0.3):
+        self.lib = load_library()
+        cfg = HpfConfig()
+        cfg.struct_size = C.sizeof(HpfConfig)
+        cfg.n_users, cfg.n_items, cfg.K = int(n_users), int(n_items), int(K)
+        cfg.hier, cfg.bias, cfg.binary = int(bool(hier)), int(bool(bias)), int(bool(binary))
+        cfg.n_users_total = int(n_users_total)
+        cfg.device, cfg.n_ranks, cfg.rank = int(device), int(n_ranks), int(rank)
+        cfg.stream = C.c_void_p(stream) if stream else None
+        cfg.s_prior, cfg.r_prior = float(s_prior), float(r_prior)
+        self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(K)
+        self.hier, self.bias, self.binary = bool(hier), bool(bias), bool(binary)
+        self._h = C.c_void_p()
+        rc = self.lib.hpf_create(C.byref(cfg), C.byref(self._h))
+        if rc != HPF_OK:
+            self._h = C.c_void_p()
+            raise HpfError(f"hpf_create failed: {self.lib.hpf_strerror(rc).decode()} ({rc})")
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != HPF_OK:
+            msg = self.lib.hpf_last_error(self._h).decode()
+            raise HpfError(f"{self.lib.hpf_strerror(rc).decode()} ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.hpf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- data
+    def upload_csr(self, rowptr, col, val=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        if rowptr.shape[0] != self.n_users + 1:
+            raise ValueError("rowptr must have n_users + 1 entries")
+        vp = None
+        if val is not None:
+            val = np.ascontiguousarray(val, dtype=np.uint8)
+            vp = _ptr(val, C.c_uint8)
+        self._check(self.lib.hpf_upload_csr(self._h, _ptr(rowptr, C.c_int64),
+                                            _ptr(col, C.c_uint32), vp))
+
+    def state_shape(self, which: str):
+        obj = STATE[which] // 4
+        kind = STATE[which] % 4
+        if obj == 0:
+            shp = (self.n_users, self.K)
+        elif obj == 1:
+            shp = (self.n_items, self.K)
+        elif obj in (2, 4):
+            shp = (self.n_users,)
+        else:
+            shp = (self.n_items,)
+        if obj <= 1 and kind == 1 and not self.hier:
+            shp = (self.K,)
+        return shp
+
+    def set_state(self, which: str, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.shape != self.state_shape(which):
+            raise ValueError(f"{which}: expected shape {self.state_shape(which)}, got {a.shape}")
+        self._check(self.lib.hpf_set_state(self._h, STATE[which], _ptr(a, C.c_double), a.size))
+
+    def get_state(self, which: str) -> np.ndarray:
+        out = np.empty(self.state_shape(which), dtype=np.float64)
+        self._check(self.lib.hpf_get_state(self._h, STATE[which], _ptr(out, C.c_double), out.size))
+        return out
+
+    # -- compute
+    def iterate(self, n_iters=1):
+        self._check(self.lib.hpf_iterate(self._h, int(n_iters)))
+
+    def iterate_local(self):
+        self._check(self.lib.hpf_iterate_local(self._h))
+
+    def iterate_global(self):
+        self._check(self.lib.hpf_iterate_global(self._h))
+
+    def exchange_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.hpf_exchange_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind_exchange_buffer(self, dev_ptr: int, count: int):
+        self._check(self.lib.hpf_bind_exchange_buffer(self._h, C.c_void_p(dev_ptr), count))
+
+    def exchange_count(self):
+        return self.exchange_buffer()[1]
+
+    def heldout_ll(self, u, i, y):
+        u = np.ascontiguousarray(u, dtype=np.uint32)
+        i = np.ascontiguousarray(i, dtype=np.uint32)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        s, c = C.c_double(), C.c_uint64()
+        self._check(self.lib.hpf_heldout_ll(self._h, _ptr(u, C.c_uint32), _ptr(i, C.c_uint32),
+                                            _ptr(y, C.c_int32), u.size, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def synchronize(self):
+        self._check(self.lib.hpf_synchronize(self._h))
+
+    def last_timing(self) -> dict:
+        t = HpfTiming()
+        self._check(self.lib.hpf_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
+
+    def algorithmic_bytes(self) -> dict:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.hpf_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"phi_user": a.value, "phi_item": b.value, "rows": c.value}

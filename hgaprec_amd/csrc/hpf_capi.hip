@@ -1,0 +1,811 @@
+// hpf_capi.hip -- implementation of include/hpf.h (libhpf_hip.so).
+// Host orchestration of the gfx950 kernels in hpf_kernels.hpp: device state,
+// CSR -> (CSR, CSC, segment lists), the per-iteration launch sequence, the
+// exchange buffer for the multi-GPU all-reduce, hipEvent timing.
+//
+// Device layout (all fp64, row stride ld = round_up(K + 2*bias, 2)):
+//   user side  theta: S,E,L,W [n x ld]   column K   = user bias (thetabias)
+//                                         column K+1 = 0 ("junk": Elog 0)
+//   item side  beta : S,E,L,W [m x ld]   column K   = junk, column K+1 = item bias
+//   xi/eta     prior_E[rows] (+ prior_used, prior_rate for export)
+//   exchange   [m x ld | ld]: item S rows followed by sum_u E[theta_u,:]
+#include "../../include/hpf.h"
+#include "hpf_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hpf;
+
+namespace {
+
+struct Side {
+  uint32_t rows = 0;
+  double *S = nullptr, *E = nullptr, *L = nullptr, *W = nullptr;
+  double *prior_E = nullptr, *prior_used = nullptr, *prior_rate = nullptr;
+  double *colsum = nullptr;       // [ld] sum over this side's rows of E
+  double *colsum_used = nullptr;  // [ld] other side's colsum used in the last rate
+  double *colsum_part = nullptr;  // [sweep_blocks x ld]
+  double *rate_set = nullptr;     // rate handed in by hpf_set_state (export before iter 0)
+  size_t  rate_set_count = 0;
+  double *prior_shape_set = nullptr, *prior_elog_set = nullptr;  // xi/eta extras
+  // phi pass work lists
+  Seg *segs = nullptr; uint32_t nseg = 0;
+  LongRow *longrows = nullptr; uint32_t nlong = 0;
+  double *partial = nullptr; uint32_t npartial = 0;
+  uint32_t *idx = nullptr; uint8_t *val = nullptr;
+  int32_t bias_col = -1, junk_col = -1;
+  double bias_rate_add = 0.0;
+  uint32_t sweep_blocks = 0;
+  bool have_E = false, have_L = false, have_prior = false;
+};
+
+}  // namespace
+
+struct hpf_handle {
+  hpf_config cfg;
+  uint32_t K = 0, C = 0, ld = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Side u, it;
+  double *exch = nullptr; size_t exch_count = 0; bool exch_external = false;
+  double *logfact = nullptr;
+  uint64_t nnz = 0;
+  bool have_csr = false, derived_dirty = true;
+  uint32_t iterations = 0;
+  int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
+  uint32_t seg_max = 512;
+  uint32_t phi_blocks = 2048;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);            \
+      return (e_ == hipErrorOutOfMemory) ? HPF_ERR_OOM : HPF_ERR_HIP;          \
+    }                                                                          \
+  } while (0)
+
+template <typename T>
+int dalloc(hpf_handle *h, T **p, size_t n)
+{
+  if (n == 0) n = 1;
+  HIPCHK(h, hipMalloc((void **)p, n * sizeof(T)));
+  HIPCHK(h, hipMemsetAsync(*p, 0, n * sizeof(T), h->stream));
+  return HPF_OK;
+}
+
+void dfree(void *p) { if (p) (void)hipFree(p); }
+
+void free_side(Side &s, bool S_external)
+{
+  if (!S_external) dfree(s.S);
+  dfree(s.E); dfree(s.L); dfree(s.W);
+  dfree(s.prior_E); dfree(s.prior_used); dfree(s.prior_rate);
+  dfree(s.colsum_used); dfree(s.colsum_part);
+  dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
+  dfree(s.segs); dfree(s.longrows); dfree(s.partial); dfree(s.idx); dfree(s.val);
+  s = Side();
+}
+
+// pick (G,R[,V]) with G*R*V >= ld, R <= 8, least padding, then fewest registers
+bool choose_cfg(uint32_t ld, int V, int *G, int *R)
+{
+  int bestG = 0, bestR = 0; long bestw = -1;
+  const int Gs[5] = {4, 8, 16, 32, 64};
+  for (int gi = 0; gi < 5; ++gi) {
+    const int g = Gs[gi];
+    const int r = (int)((ld + (uint32_t)(g * V) - 1) / (uint32_t)(g * V));
+    if (r < 1 || r > 8) continue;
+    const long w = (long)g * r * V - (long)ld;
+    if (bestw < 0 || w < bestw || (w == bestw && r < bestR)) { bestw = w; bestG = g; bestR = r; }
+  }
+  if (bestw < 0) return false;
+  *G = bestG; *R = bestR;
+  return true;
+}
+
+// ---- kernel dispatch over the template grid -------------------------------
+template <int G, int R, int V>
+void launch_phi_t(const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  hipLaunchKernelGGL((phi_pass_kernel<G, R, V>), dim3(blocks), dim3(256), 0, st, a);
+}
+template <int G, int V>
+bool launch_phi_r(int R, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (R) {
+    case 1: launch_phi_t<G, 1, V>(a, blocks, st); return true;
+    case 2: launch_phi_t<G, 2, V>(a, blocks, st); return true;
+    case 3: launch_phi_t<G, 3, V>(a, blocks, st); return true;
+    case 4: launch_phi_t<G, 4, V>(a, blocks, st); return true;
+    case 5: launch_phi_t<G, 5, V>(a, blocks, st); return true;
+    case 6: launch_phi_t<G, 6, V>(a, blocks, st); return true;
+    case 7: launch_phi_t<G, 7, V>(a, blocks, st); return true;
+    case 8: launch_phi_t<G, 8, V>(a, blocks, st); return true;
+  }
+  return false;
+}
+template <int V>
+bool launch_phi_g(int G, int R, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_phi_r<4, V>(R, a, blocks, st);
+    case 8:  return launch_phi_r<8, V>(R, a, blocks, st);
+    case 16: return launch_phi_r<16, V>(R, a, blocks, st);
+    case 32: return launch_phi_r<32, V>(R, a, blocks, st);
+    case 64: return launch_phi_r<64, V>(R, a, blocks, st);
+  }
+  return false;
+}
+bool launch_phi(int G, int R, int V, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  return V == 2 ? launch_phi_g<2>(G, R, a, blocks, st) : launch_phi_g<1>(G, R, a, blocks, st);
+}
+
+template <int G>
+bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+{
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR>), dim3(blocks), dim3(256), 0, st, a); return true;
+  switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
+#undef SW
+  return false;
+}
+bool launch_sweep(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_sweep_r<4>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64>(R, a, blocks, st);
+  }
+  return false;
+}
+
+int check_launch(hpf_handle *h, const char *what)
+{
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return HPF_ERR_HIP;
+  }
+  return HPF_OK;
+}
+
+// ---- work lists -----------------------------------------------------------
+void build_segments(const int64_t *ptr, uint32_t rows, uint32_t seg_max,
+                    std::vector<Seg> &segs, std::vector<LongRow> &longs,
+                    uint32_t *npartial)
+{
+  segs.clear(); longs.clear();
+  uint32_t slot = 0;
+  for (uint32_t r = 0; r < rows; ++r) {
+    const int64_t a = ptr[r], b = ptr[r + 1];
+    const uint64_t deg = (uint64_t)(b - a);
+    if (deg <= seg_max) {
+      Seg s; s.start = a; s.row = r; s.len = (uint32_t)deg; s.pslot = -1; s.pad = 0;
+      segs.push_back(s);
+    } else {
+      const uint32_t ns = (uint32_t)((deg + seg_max - 1) / seg_max);
+      LongRow lr; lr.row = r; lr.first_slot = slot; lr.nslots = ns; lr.pad = 0;
+      longs.push_back(lr);
+      for (uint32_t k = 0; k < ns; ++k) {
+        Seg s; s.start = a + (int64_t)k * seg_max; s.row = r;
+        s.len = (uint32_t)std::min<uint64_t>(seg_max, deg - (uint64_t)k * seg_max);
+        s.pslot = (int32_t)slot++; s.pad = 0;
+        segs.push_back(s);
+      }
+    }
+  }
+  *npartial = slot;
+}
+
+int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
+                     const uint32_t *idx, const uint8_t *val, uint64_t nnz)
+{
+  std::vector<Seg> segs; std::vector<LongRow> longs; uint32_t np = 0;
+  build_segments(ptr, rows, h->seg_max, segs, longs, &np);
+  dfree(s.segs); dfree(s.longrows); dfree(s.partial); dfree(s.idx); dfree(s.val);
+  s.segs = nullptr; s.longrows = nullptr; s.partial = nullptr; s.idx = nullptr; s.val = nullptr;
+  s.nseg = (uint32_t)segs.size(); s.nlong = (uint32_t)longs.size(); s.npartial = np;
+  int rc;
+  if ((rc = dalloc(h, &s.segs, segs.size()))) return rc;
+  if ((rc = dalloc(h, &s.longrows, longs.size()))) return rc;
+  if ((rc = dalloc(h, &s.partial, (size_t)np * h->ld))) return rc;
+  if ((rc = dalloc(h, &s.idx, (size_t)nnz))) return rc;
+  if (!segs.empty())
+    HIPCHK(h, hipMemcpyAsync(s.segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, h->stream));
+  if (!longs.empty())
+    HIPCHK(h, hipMemcpyAsync(s.longrows, longs.data(), longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+  if (nnz)
+    HIPCHK(h, hipMemcpyAsync(s.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  if (val) {
+    if ((rc = dalloc(h, &s.val, (size_t)nnz))) return rc;
+    if (nnz)
+      HIPCHK(h, hipMemcpyAsync(s.val, val, nnz, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // host vectors die here
+  return HPF_OK;
+}
+
+// dense [rows x cols] host <-> padded device column block.  Wide blocks go
+// through a strided DMA; single columns (bias objects) are staged through a
+// contiguous device buffer and a scatter/gather kernel (a 2-D copy of 8-byte
+// rows is one descriptor per row).
+int copy_in(hpf_handle *h, double *dev, uint32_t ld, uint32_t col0, const double *host,
+            uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == 1) {
+    double *tmp = nullptr; int rc;
+    if ((rc = dalloc(h, &tmp, rows))) return rc;
+    hipError_t e = hipMemcpyAsync(tmp, host, (size_t)rows * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(column_scatter_kernel, dim3(std::min<uint32_t>((rows + 255) / 256, 4096)),
+                         dim3(256), 0, h->stream, tmp, dev + col0, rows, ld);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(tmp);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
+    return HPF_OK;
+  }
+  HIPCHK(h, hipMemcpy2DAsync(dev + col0, (size_t)ld * 8, host, (size_t)cols * 8, (size_t)cols * 8,
+                             rows, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+int copy_out(hpf_handle *h, const double *dev, uint32_t ld, uint32_t col0, double *host,
+             uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == 1) {
+    double *tmp = nullptr; int rc;
+    if ((rc = dalloc(h, &tmp, rows))) return rc;
+    hipLaunchKernelGGL(column_gather_kernel, dim3(std::min<uint32_t>((rows + 255) / 256, 4096)),
+                       dim3(256), 0, h->stream, dev + col0, tmp, rows, ld);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, tmp, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(tmp);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
+    return HPF_OK;
+  }
+  HIPCHK(h, hipMemcpy2DAsync(host, (size_t)cols * 8, dev + col0, (size_t)ld * 8, (size_t)cols * 8,
+                             rows, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
+// host digamma for the xi/eta Elog export (same series as the device one)
+double host_digamma(double x)
+{
+  double acc = 0.0;
+  while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
+  const double xi = 1.0 / x, x2 = xi * xi;
+  double s = x2 * (1.0 / 12 - x2 * (1.0 / 120 - x2 * (1.0 / 252 - x2 * (1.0 / 240 -
+             x2 * (1.0 / 132 - x2 * (691.0 / 32760 - x2 * (1.0 / 12)))))));
+  return acc + std::log(x) - 0.5 * xi - s;
+}
+
+int prepare_derived(hpf_handle *h)
+{
+  if (!h->derived_dirty) return HPF_OK;
+  if (!(h->u.have_L && h->it.have_L && h->it.have_E)) {
+    h->err = "state not initialised: set THETA_ELOG, BETA_ELOG and BETA_E before iterating";
+    return HPF_ERR_STATE;
+  }
+  if (h->cfg.hier && !(h->u.have_prior && h->it.have_prior)) {
+    h->err = "state not initialised: set XI_E and ETA_E (-hier)";
+    return HPF_ERR_STATE;
+  }
+  Side *sides[2] = {&h->u, &h->it};
+  for (Side *s : sides) {
+    if (!s->rows) continue;
+    const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
+    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
+                       s->rows, h->ld, h->K, s->bias_col, s->junk_col);
+  }
+  // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
+  {
+    Side &s = h->it;
+    const uint32_t nb = s.sweep_blocks;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, h->stream, s.E, s.rows,
+                       h->ld, h->K, s.colsum_part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((h->ld + 63) / 64), dim3(64), 0, h->stream,
+                       s.colsum_part, nb, h->ld, s.colsum);
+  }
+  int rc = check_launch(h, "prepare_derived");
+  if (rc) return rc;
+  h->derived_dirty = false;
+  return HPF_OK;
+}
+
+int run_phi(hpf_handle *h, Side &own, Side &oth)
+{
+  PhiArgs a;
+  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
+  a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
+  if (own.nseg) {
+    const uint32_t blocks = std::min<uint32_t>((own.nseg + 3) / 4, h->phi_blocks);
+    if (!launch_phi(h->phiG, h->phiR, h->phiV, a, blocks, h->stream)) {
+      h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
+    }
+  }
+  if (own.nlong) {
+    const uint32_t blocks = std::min<uint32_t>(own.nlong, 4096);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(128), 0, h->stream,
+                       own.longrows, own.nlong, own.partial, own.S, h->ld);
+  }
+  return check_launch(h, "phi pass");
+}
+
+int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_out)
+{
+  // remember what the rate was built from (export of *_rate.tsv)
+  HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
+  SweepArgs a;
+  a.S = s.S; a.E = s.E; a.L = s.L; a.W = s.W;
+  a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
+  a.colsum_oth = colsum_oth; a.colsum_part = s.colsum_part;
+  a.rows = s.rows; a.ld = h->ld; a.K = h->K;
+  a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
+  a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
+  if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
+    h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((h->ld + 63) / 64), dim3(64), 0, h->stream,
+                     s.colsum_part, s.sweep_blocks, h->ld, colsum_out);
+  return check_launch(h, "row sweep");
+}
+
+int iterate_local(hpf_handle *h)
+{
+  int rc;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if ((rc = prepare_derived(h))) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  if ((rc = run_phi(h, h->u, h->it))) return rc;           // step A, theta shape sums
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  if ((rc = run_phi(h, h->it, h->u))) return rc;           // step A, beta shape sums
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  // steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits d = sum_u E[theta]
+  if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  return HPF_OK;
+}
+
+int iterate_global(hpf_handle *h)
+{
+  int rc;
+  // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
+  if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+  h->ev_valid = true;
+  h->iterations++;
+  return HPF_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int hpf_abi_version(void) { return HPF_ABI_VERSION; }
+
+const char *hpf_strerror(int st)
+{
+  switch (st) {
+    case HPF_OK: return "ok";
+    case HPF_ERR_INVALID: return "invalid argument or call order";
+    case HPF_ERR_NO_DEVICE: return "no usable HIP device";
+    case HPF_ERR_OOM: return "out of memory";
+    case HPF_ERR_HIP: return "HIP runtime error";
+    case HPF_ERR_UNSUPPORTED: return "unsupported configuration";
+    case HPF_ERR_STATE: return "model state not initialised";
+  }
+  return "unknown status";
+}
+
+const char *hpf_last_error(const hpf_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int hpf_create(const hpf_config *cfg, hpf_handle **out)
+{
+  if (!cfg || !out) return HPF_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(hpf_config)) return HPF_ERR_INVALID;
+  if (cfg->K == 0 || cfg->n_items == 0) return HPF_ERR_INVALID;
+  if (cfg->n_ranks == 0 || cfg->rank >= cfg->n_ranks) return HPF_ERR_INVALID;
+  const uint32_t C = cfg->K + (cfg->bias ? 2u : 0u);
+  if (C > HPF_MAX_COLUMNS) return HPF_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HPF_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return HPF_ERR_NO_DEVICE;
+  if (hipSetDevice(cfg->device) != hipSuccess) return HPF_ERR_NO_DEVICE;
+
+  hpf_handle *h = new (std::nothrow) hpf_handle();
+  if (!h) return HPF_ERR_OOM;
+  h->cfg = *cfg;
+  if (h->cfg.n_users_total == 0) h->cfg.n_users_total = cfg->n_users;
+  if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
+  if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
+  h->K = cfg->K; h->C = C; h->ld = (C + 1u) & ~1u;
+
+  auto fail = [&](int rc) { hpf_destroy(h); return rc; };
+  if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+  else {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_ERR_HIP);
+    h->own_stream = true;
+  }
+  for (int e = 0; e < 5; ++e)
+    if (hipEventCreate(&h->ev[e]) != hipSuccess) return fail(HPF_ERR_HIP);
+
+  // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
+  h->phiV = 1;
+  if (!choose_cfg(h->ld, 1, &h->phiG, &h->phiR)) return fail(HPF_ERR_UNSUPPORTED);
+  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR)) return fail(HPF_ERR_UNSUPPORTED);
+  if (const char *e = getenv("HPF_PHI_CFG")) {
+    int g = 0, r = 0, v = 0;
+    if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (v == 1 || v == 2) && r >= 1 && r <= 8 &&
+        (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && (uint32_t)(g * r * v) >= h->ld) {
+      h->phiG = g; h->phiR = r; h->phiV = v;
+    } else if (sscanf(e, "v%d", &v) == 1 && (v == 1 || v == 2)) {
+      int g2, r2;
+      if (choose_cfg(h->ld, v, &g2, &r2)) { h->phiG = g2; h->phiR = r2; h->phiV = v; }
+    }
+  }
+  if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
+  if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
+
+  const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
+  h->u.rows = n; h->it.rows = m;
+  if (cfg->bias) {
+    h->u.bias_col = (int32_t)h->K;      h->u.junk_col = (int32_t)h->K + 1;
+    h->it.bias_col = (int32_t)h->K + 1; h->it.junk_col = (int32_t)h->K;
+    h->u.bias_rate_add = (double)m;                       // hgaprec.cc:1389 (0.3 + m)
+    h->it.bias_rate_add = (double)h->cfg.n_users_total;   // hgaprec.cc:1393 (0.3 + n)
+  }
+  int rc;
+  Side *sides[2] = {&h->u, &h->it};
+  for (Side *s : sides) {
+    const size_t ne = (size_t)s->rows * ld;
+    const uint32_t gpb = 256u / (uint32_t)h->swG;         // groups (rows) per block
+    s->sweep_blocks = std::max<uint32_t>(1, std::min<uint32_t>((s->rows + gpb - 1) / gpb, 1024));
+    if (s == &h->u) { if ((rc = dalloc(h, &s->S, ne))) return fail(rc); }
+    if ((rc = dalloc(h, &s->E, ne))) return fail(rc);
+    if ((rc = dalloc(h, &s->L, ne))) return fail(rc);
+    if ((rc = dalloc(h, &s->W, ne))) return fail(rc);
+    if ((rc = dalloc(h, &s->prior_E, s->rows))) return fail(rc);
+    if ((rc = dalloc(h, &s->prior_used, s->rows))) return fail(rc);
+    if ((rc = dalloc(h, &s->prior_rate, s->rows))) return fail(rc);
+    if ((rc = dalloc(h, &s->colsum_used, ld))) return fail(rc);
+    if ((rc = dalloc(h, &s->colsum_part, (size_t)s->sweep_blocks * ld))) return fail(rc);
+  }
+  // exchange buffer: item S rows | sum_u E[theta]   (+ item colsum kept apart)
+  h->exch_count = (size_t)m * ld + ld;
+  if ((rc = dalloc(h, &h->exch, h->exch_count))) return fail(rc);
+  h->it.S = h->exch; h->u.colsum = h->exch + (size_t)m * ld;
+  if ((rc = dalloc(h, &h->it.colsum, ld))) return fail(rc);
+  // log y! as HGAPRec::log_factorial does it (hgaprec.cc:1563-1570)
+  {
+    double lf[256]; lf[0] = std::log(1.0); lf[1] = lf[0];
+    for (uint32_t y = 2; y < 256; ++y) lf[y] = lf[y - 1] + std::log((double)y);
+    if ((rc = dalloc(h, &h->logfact, 256))) return fail(rc);
+    if (hipMemcpyAsync(h->logfact, lf, sizeof lf, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
+  }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
+  *out = h;
+  return HPF_OK;
+}
+
+void hpf_destroy(hpf_handle *h)
+{
+  if (!h) return;
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
+  h->u.colsum = nullptr;
+  double *icol = h->it.colsum; h->it.colsum = nullptr;
+  free_side(h->u, false);
+  free_side(h->it, true);
+  dfree(icol);
+  if (!h->exch_external) dfree(h->exch);
+  dfree(h->logfact);
+  for (int e = 0; e < 5; ++e) if (h->ev[e]) (void)hipEventDestroy(h->ev[e]);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int hpf_bind_exchange_buffer(hpf_handle *h, void *dev, size_t count)
+{
+  if (!h || !dev) return HPF_ERR_INVALID;
+  if (count < h->exch_count || ((uintptr_t)dev & 15u)) { h->err = "exchange buffer too small or misaligned"; return HPF_ERR_INVALID; }
+  if (h->have_csr || h->iterations) { h->err = "bind the exchange buffer before hpf_upload_csr"; return HPF_ERR_INVALID; }
+  HIPCHK(h, hipMemsetAsync(dev, 0, h->exch_count * 8, h->stream));
+  // keep any item shapes already handed in
+  HIPCHK(h, hipMemcpyAsync(dev, h->exch, h->exch_count * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->exch_external) dfree(h->exch);
+  h->exch = (double *)dev; h->exch_external = true;
+  h->it.S = h->exch; h->u.colsum = h->exch + (size_t)h->it.rows * h->ld;
+  return HPF_OK;
+}
+
+int hpf_exchange_buffer(hpf_handle *h, void **dev, size_t *count)
+{
+  if (!h || !dev || !count) return HPF_ERR_INVALID;
+  *dev = h->exch; *count = h->exch_count;
+  return HPF_OK;
+}
+
+int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, const uint8_t *val)
+{
+  if (!h || !rowptr) return HPF_ERR_INVALID;
+  const uint32_t n = h->u.rows, m = h->it.rows;
+  if (rowptr[0] != 0) { h->err = "rowptr[0] must be 0"; return HPF_ERR_INVALID; }
+  for (uint32_t r = 0; r < n; ++r)
+    if (rowptr[r + 1] < rowptr[r]) { h->err = "rowptr not monotone"; return HPF_ERR_INVALID; }
+  const uint64_t nnz = (uint64_t)rowptr[n];
+  if (nnz && !col) return HPF_ERR_INVALID;
+  // item-major view: counting sort by item keeps users ascending inside an
+  // item, i.e. the order in which the reference's serial loop reaches them
+  std::vector<int64_t> colptr((size_t)m + 1, 0);
+  for (uint64_t j = 0; j < nnz; ++j) {
+    if (col[j] >= m) { h->err = "item index out of range"; return HPF_ERR_INVALID; }
+    colptr[(size_t)col[j] + 1]++;
+  }
+  for (uint32_t i = 0; i < m; ++i) colptr[i + 1] += colptr[i];
+  std::vector<uint32_t> cuser((size_t)nnz);
+  std::vector<uint8_t> cval(val ? (size_t)nnz : 0);
+  {
+    std::vector<int64_t> next(colptr.begin(), colptr.end() - 1);
+    for (uint32_t u = 0; u < n; ++u)
+      for (int64_t j = rowptr[u]; j < rowptr[u + 1]; ++j) {
+        const int64_t p = next[col[j]]++;
+        cuser[(size_t)p] = u;
+        if (val) cval[(size_t)p] = val[j];
+      }
+  }
+  int rc;
+  if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz))) return rc;
+  if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz))) return rc;
+  h->nnz = nnz; h->have_csr = true;
+  return HPF_OK;
+}
+
+static int state_dims(const hpf_handle *h, int which, Side **side, uint32_t *rows, uint32_t *cols,
+                      int *col0, int *kind)
+{
+  const int obj = which / 4; *kind = which % 4;
+  hpf_handle *hh = const_cast<hpf_handle *>(h);
+  switch (obj) {
+    case 0: *side = &hh->u;  *rows = h->u.rows;  *cols = h->K; *col0 = 0; return 0;
+    case 1: *side = &hh->it; *rows = h->it.rows; *cols = h->K; *col0 = 0; return 0;
+    case 2: if (!h->cfg.hier) return -1; *side = &hh->u;  *rows = h->u.rows;  *cols = 1; *col0 = -1; return 0;
+    case 3: if (!h->cfg.hier) return -1; *side = &hh->it; *rows = h->it.rows; *cols = 1; *col0 = -1; return 0;
+    case 4: if (!h->cfg.bias) return -1; *side = &hh->u;  *rows = h->u.rows;  *cols = 1; *col0 = h->u.bias_col; return 0;
+    case 5: if (!h->cfg.bias) return -1; *side = &hh->it; *rows = h->it.rows; *cols = 1; *col0 = h->it.bias_col; return 0;
+  }
+  return -1;
+}
+
+int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t count)
+{
+  if (!h || !host || which < 0 || which >= HPF_NUM_STATE) return HPF_ERR_INVALID;
+  Side *s; uint32_t rows, cols; int col0, kind;
+  if (state_dims(h, which, &s, &rows, &cols, &col0, &kind)) { h->err = "state not part of this model"; return HPF_ERR_INVALID; }
+  const int obj = which / 4;
+  int rc;
+  if (obj == 2 || obj == 3) {                 // xi / eta vectors
+    if (count != rows) return HPF_ERR_INVALID;
+    double **dst = nullptr;
+    switch (kind) {
+      case 0: dst = &s->prior_shape_set; break;
+      case 1: dst = &s->prior_rate; break;
+      case 2: dst = &s->prior_E; s->have_prior = true; break;
+      default: dst = &s->prior_elog_set; break;
+    }
+    if (!*dst && (rc = dalloc(h, dst, rows))) return rc;
+    HIPCHK(h, hipMemcpyAsync(*dst, host, (size_t)rows * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
+  const bool gr_rate = (obj <= 1 && kind == 1 && !h->cfg.hier);
+  if (kind == 1) {                            // rate: kept only for export before iteration 0
+    const size_t want = gr_rate ? h->K : (size_t)rows * cols;
+    if (count != want) return HPF_ERR_INVALID;
+    if (obj >= 4) return HPF_OK;              // bias rate is the constant 0.3 + m / 0.3 + n
+    dfree(s->rate_set); s->rate_set = nullptr;
+    if ((rc = dalloc(h, &s->rate_set, want))) return rc;
+    s->rate_set_count = want;
+    HIPCHK(h, hipMemcpyAsync(s->rate_set, host, want * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
+  if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
+  double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
+  if ((rc = copy_in(h, dev, h->ld, (uint32_t)col0, host, rows, cols))) return rc;
+  if (obj <= 1) {
+    if (kind == 2) s->have_E = true;
+    if (kind == 3) s->have_L = true;
+  }
+  if (kind != 0) h->derived_dirty = true;
+  return HPF_OK;
+}
+
+int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
+{
+  if (!h || !host || which < 0 || which >= HPF_NUM_STATE) return HPF_ERR_INVALID;
+  Side *s; uint32_t rows, cols; int col0, kind;
+  if (state_dims(h, which, &s, &rows, &cols, &col0, &kind)) { h->err = "state not part of this model"; return HPF_ERR_INVALID; }
+  const int obj = which / 4;
+  const double s0 = h->cfg.s_prior, r0 = h->cfg.r_prior;
+  if (obj == 2 || obj == 3) {
+    if (count != rows) return HPF_ERR_INVALID;
+    if (kind == 2 || kind == 1) {
+      const double *src = kind == 2 ? s->prior_E : s->prior_rate;
+      HIPCHK(h, hipMemcpyAsync(host, src, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      return HPF_OK;
+    }
+    if (h->iterations == 0) {
+      const double *src = kind == 0 ? s->prior_shape_set : s->prior_elog_set;
+      if (!src) { h->err = "state was never set"; return HPF_ERR_STATE; }
+      HIPCHK(h, hipMemcpyAsync(host, src, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      return HPF_OK;
+    }
+    // after a sweep: shape = s0 + K*s0 (gpbase.hh:877-882), Elog = psi(shape) - log(rate)
+    const double sh = s0 + (double)h->K * s0;
+    if (kind == 0) { for (uint32_t r = 0; r < rows; ++r) host[r] = sh; return HPF_OK; }
+    HIPCHK(h, hipMemcpyAsync(host, s->prior_rate, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const double ps = host_digamma(sh);
+    for (uint32_t r = 0; r < rows; ++r) host[r] = ps - std::log(host[r]);
+    return HPF_OK;
+  }
+  if (kind == 1) {                            // rate
+    const bool gr = (obj <= 1 && !h->cfg.hier);
+    const size_t want = gr ? h->K : (size_t)rows * cols;
+    if (count != want) return HPF_ERR_INVALID;
+    if (obj >= 4) {                           // gpbase.hh:225-231 via hgaprec.cc:1389,1393
+      if (h->iterations == 0) { h->err = "bias rate is defined after the first sweep"; return HPF_ERR_STATE; }
+      for (uint32_t r = 0; r < rows; ++r) host[r] = r0 + s->bias_rate_add;
+      return HPF_OK;
+    }
+    if (h->iterations == 0) {
+      if (!s->rate_set || s->rate_set_count != want) { h->err = "state was never set"; return HPF_ERR_STATE; }
+      HIPCHK(h, hipMemcpyAsync(host, s->rate_set, want * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      return HPF_OK;
+    }
+    if (gr) {                                 // r_k = 0.3 + colsum_k  (gpbase.hh:558-562)
+      std::vector<double> cs(h->ld);
+      HIPCHK(h, hipMemcpyAsync(cs.data(), s->colsum_used, (size_t)h->ld * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (uint32_t k = 0; k < h->K; ++k) host[k] = r0 + cs[k];
+      return HPF_OK;
+    }
+    double *tmp = nullptr; int rc;
+    if ((rc = dalloc(h, &tmp, want))) return rc;
+    hipLaunchKernelGGL(build_rate_kernel, dim3(1024), dim3(256), 0, h->stream, s->prior_used,
+                       s->colsum_used, rows, h->K, tmp);
+    rc = check_launch(h, "build_rate");
+    if (!rc) {
+      hipError_t e = hipMemcpyAsync(host, tmp, want * 8, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; }
+    }
+    dfree(tmp);
+    return rc;
+  }
+  if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
+  const double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
+  return copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
+}
+
+int hpf_iterate(hpf_handle *h, int n_iters)
+{
+  if (!h || n_iters < 0) return HPF_ERR_INVALID;
+  if (h->cfg.n_ranks != 1) { h->err = "hpf_iterate needs n_ranks == 1; use iterate_local/global"; return HPF_ERR_INVALID; }
+  for (int t = 0; t < n_iters; ++t) {
+    int rc;
+    if ((rc = iterate_local(h))) return rc;
+    if ((rc = iterate_global(h))) return rc;
+  }
+  return HPF_OK;
+}
+
+int hpf_iterate_local(hpf_handle *h) { return h ? iterate_local(h) : HPF_ERR_INVALID; }
+int hpf_iterate_global(hpf_handle *h) { return h ? iterate_global(h) : HPF_ERR_INVALID; }
+
+int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const int32_t *y,
+                   size_t cnt, double *sum_out, uint64_t *cnt_out)
+{
+  if (!h || !sum_out) return HPF_ERR_INVALID;
+  *sum_out = 0.0; if (cnt_out) *cnt_out = cnt;
+  if (cnt == 0) return HPF_OK;
+  if (!u || !i || !y) return HPF_ERR_INVALID;
+  if (!(h->u.have_E && h->it.have_E) && h->iterations == 0) { h->err = "E state not set"; return HPF_ERR_STATE; }
+  for (size_t p = 0; p < cnt; ++p)
+    if (u[p] >= h->u.rows || i[p] >= h->it.rows) { h->err = "held-out index out of range"; return HPF_ERR_INVALID; }
+  uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr;
+  int rc = HPF_OK;
+  std::vector<double> out(cnt);
+  do {
+    if ((rc = dalloc(h, &du, cnt)) || (rc = dalloc(h, &di, cnt)) || (rc = dalloc(h, &dy, cnt)) ||
+        (rc = dalloc(h, &dout, cnt))) break;
+    hipError_t e = hipMemcpyAsync(du, u, cnt * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(di, i, cnt * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dy, y, cnt * 4, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    LLArgs a;
+    a.u = du; a.i = di; a.y = dy; a.cnt = cnt; a.Et = h->u.E; a.Eb = h->it.E;
+    a.logfact = h->logfact; a.out = dout; a.ld = h->ld; a.K = h->K;
+    a.ubias_col = h->cfg.bias ? h->u.bias_col : -1;
+    a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
+    a.binary = h->cfg.binary;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((cnt + 15) / 16, 4096);
+    hipLaunchKernelGGL(heldout_ll_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+    if ((rc = check_launch(h, "heldout_ll"))) break;
+    e = hipMemcpyAsync(out.data(), dout, cnt * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    double s = .0;                       // serial, in map order: hgaprec.cc:1455-1465
+    for (size_t p = 0; p < cnt; ++p) s += out[p];
+    *sum_out = s;
+  } while (0);
+  dfree(du); dfree(di); dfree(dy); dfree(dout);
+  return rc;
+}
+
+int hpf_synchronize(hpf_handle *h)
+{
+  if (!h) return HPF_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
+int hpf_last_timing(hpf_handle *h, hpf_timing *out)
+{
+  if (!h || !out) return HPF_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->iterations = h->iterations;
+  if (!h->ev_valid) return HPF_OK;
+  HIPCHK(h, hipEventSynchronize(h->ev[4]));
+  HIPCHK(h, hipEventElapsedTime(&out->phi_user_ms, h->ev[0], h->ev[1]));
+  HIPCHK(h, hipEventElapsedTime(&out->phi_item_ms, h->ev[1], h->ev[2]));
+  HIPCHK(h, hipEventElapsedTime(&out->sweep_user_ms, h->ev[2], h->ev[3]));
+  HIPCHK(h, hipEventElapsedTime(&out->sweep_item_ms, h->ev[3], h->ev[4]));
+  HIPCHK(h, hipEventElapsedTime(&out->iteration_ms, h->ev[0], h->ev[4]));
+  return HPF_OK;
+}
+
+int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item, uint64_t *rows)
+{
+  if (!h) return HPF_ERR_INVALID;
+  // SURVEY.md 8(d) with s_e = s_a = 8 and K' = K + (bias ? 1 : 0).  The
+  // item-side accumulate term nnz*K'*s_a of that formula is, in this
+  // formulation, the gather of the item pass (same byte count); the item pass
+  // is credited with that term only (its own index / row traffic is not
+  // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
+  const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
+  const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
+  if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * 8 + n * Kp * 16;
+  if (phi_item) *phi_item = nnz * Kp * 8;
+  if (rows) *rows = (n + m) * Kp * 32 + 64 * (n + m);
+  return HPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,495 @@
+// hpf_kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels for the
+// hgaprec CAVI inner loop.  No MFMA: the path is gather / elementwise /
+// small-group reduction work, HBM- and L2-bound.
+//
+// Formulation.  The reference computes, per nonzero (u,i,y)
+//   phi_k = y * exp(x_k - logsumexp(x)),  x_k = Elog_theta[u,k] + Elog_beta[i,k]
+// (hgaprec.cc:206-239 get_phi, matrix.hh:367-389 logsum/lognormalize) and adds
+// phi to the shape rows of u and of i (gpbase.hh:175-180).  Because
+// exp(a+b) = exp(a)exp(b) and the softmax is invariant to a per-row factor,
+// the row sweeps store W = exp(Elog - rowmax(Elog)) once per matrix element
+// and the per-nonzero work becomes
+//   e_k = Wt[u,k] * Wb[i,k];   phi_k = y * e_k / sum_j e_j
+// -- no transcendental in the nnz*K loop.  The two shape scatters become two
+// gather passes (user-major over CSR, item-major over CSC) so that every
+// shape row is produced by exactly one owner in a fixed order: no atomics,
+// bit-reproducible results.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpf {
+
+// ---------------------------------------------------------------------
+// work item of a phi pass: up to seg_max consecutive nonzeros of ONE owner row
+// ---------------------------------------------------------------------
+struct Seg {
+  int64_t  start;   // first nonzero (index into idx/val)
+  uint32_t row;     // owner row
+  uint32_t len;     // nonzeros in this segment (may be 0 for an empty row)
+  int32_t  pslot;   // >= 0: write the partial sum to partial[pslot] (long row)
+                    //  < 0: the row is a single segment, write S[row] directly
+  uint32_t pad;
+};
+
+struct LongRow { uint32_t row; uint32_t first_slot; uint32_t nslots; uint32_t pad; };
+
+// ---------------------------------------------------------------------
+// cross-lane helpers (wave64).  DPP moves for spans inside a 16-lane row,
+// ds_bpermute (via __shfl_xor) across rows.
+// ---------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over aligned groups of G lanes; every lane of the group gets the total
+template <int G>
+__device__ __forceinline__ double group_sum(double v)
+{
+  if (G >= 2)  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+  if (G >= 4)  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+  if (G >= 8)  v += dpp_mov<0x141>(v);   // row_half_mirror      : quad ^ 1
+  if (G >= 16) v += dpp_mov<0x140>(v);   // row_mirror           : half ^ 1
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ double group_max(double v)
+{
+  if (G >= 2)  v = fmax(v, dpp_mov<0xB1>(v));
+  if (G >= 4)  v = fmax(v, dpp_mov<0x4E>(v));
+  if (G >= 8)  v = fmax(v, dpp_mov<0x141>(v));
+  if (G >= 16) v = fmax(v, dpp_mov<0x140>(v));
+  if (G >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+  if (G >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------
+// K1: phi pass.  Template: G lanes per nonzero, R loads per lane, V doubles
+// per load (8- or 16-byte loads).  Lane g of a group owns columns
+//   (g + G*t)*V + v ,  t < R, v < V            (needs G*R*V >= ld)
+// A wave walks one segment; its 64/G groups take consecutive nonzeros, so a
+// "batch" is 64/G nonzeros.  Row of W_other for the next batch is loaded
+// before the current batch is reduced (software prefetch).
+// ---------------------------------------------------------------------
+template <int V> struct vecd;
+template <> struct vecd<1> { double x[1]; };
+template <> struct __attribute__((aligned(16))) vecd<2> { double x[2]; };
+
+struct PhiArgs {
+  const Seg      *segs;
+  uint32_t        nseg;
+  const uint32_t *idx;      // other-side row of each nonzero
+  const uint8_t  *val;      // rating (NULL: all ones)
+  const double   *W_own;    // [rows_own x ld]
+  const double   *W_oth;    // [rows_oth x ld]
+  double         *S_own;    // [rows_own x ld]  raw sums (prior added by sweep)
+  double         *partial;  // [npartial x ld]
+  uint32_t        ld;       // row stride in doubles (even)
+};
+
+template <int G, int R, int V>
+__global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
+{
+  constexpr int NG = 64 / G;             // nonzeros per batch
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G;                // column lane
+  const int q = lane / G;                // group = nonzero slot in a batch
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t ld = a.ld;
+
+  // column offsets of this lane and their validity (col < ld)
+  bool cok[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) cok[t] = (uint32_t)((g + G * t) * V) < ld;
+
+  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+    const Seg sg = a.segs[s];
+    const uint32_t len = sg.len;
+    const int64_t start = sg.start;
+
+    vecd<V> own[R], acc[R];
+    const double *wo = a.W_own + (size_t)sg.row * ld + (size_t)g * V;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      if (cok[t]) own[t] = *reinterpret_cast<const vecd<V> *>(wo + (size_t)G * t * V);
+      else
+#pragma unroll
+        for (int v = 0; v < V; ++v) own[t].x[v] = 0.0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[t].x[v] = 0.0;
+    }
+
+    if (len > 0) {
+      // indices / ratings of the current and next chunk of 64 nonzeros
+      uint32_t cur_i = ((uint32_t)lane < len) ? a.idx[start + lane] : 0u;
+      uint32_t cur_y = (a.val && (uint32_t)lane < len) ? a.val[start + lane] : 1u;
+      uint32_t nxt_i = (64u + lane < len) ? a.idx[start + 64 + lane] : 0u;
+      uint32_t nxt_y = (a.val && 64u + lane < len) ? a.val[start + 64 + lane] : 1u;
+
+      const uint32_t nb = (len + NG - 1) / NG;      // batches
+      // prefetch batch 0
+      uint32_t in = __shfl(cur_i, q, 64);
+      uint32_t yn = __shfl(cur_y, q, 64);
+      vecd<V> xn[R];
+      {
+        const double *p = a.W_oth + (size_t)in * ld + (size_t)g * V;
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+          if (cok[t]) xn[t] = *reinterpret_cast<const vecd<V> *>(p + (size_t)G * t * V);
+      }
+
+      for (uint32_t bb = 0; bb < nb; ++bb) {
+        vecd<V> x[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = xn[t];
+        const uint32_t y = yn;
+        const bool act = bb * NG + q < len;
+
+        // ---- issue the loads of batch bb+1
+        const uint32_t b1 = bb + 1;
+        if (b1 < nb) {
+          if ((b1 % G) == 0) {          // entering the next chunk of 64
+            cur_i = nxt_i; cur_y = nxt_y;
+            const uint32_t o = (b1 / G + 1) * 64u + lane;
+            nxt_i = (o < len) ? a.idx[start + o] : 0u;
+            nxt_y = (a.val && o < len) ? a.val[start + o] : 1u;
+          }
+          const int src = (int)((b1 % G) * NG + q);
+          in = __shfl(cur_i, src, 64);
+          yn = __shfl(cur_y, src, 64);
+          const double *p = a.W_oth + (size_t)in * ld + (size_t)g * V;
+#pragma unroll
+          for (int t = 0; t < R; ++t)
+            if (cok[t]) xn[t] = *reinterpret_cast<const vecd<V> *>(p + (size_t)G * t * V);
+        }
+
+        // ---- batch bb: e = W_own * W_oth ; phi = y * e / sum(e)
+        double ssum = 0.0;
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            double e = cok[t] ? own[t].x[v] * x[t].x[v] : 0.0;
+            x[t].x[v] = e;
+            ssum += e;
+          }
+        ssum = group_sum<G>(ssum);
+        // y == 0 (a rating that wrapped to 0 in the reference's uint8 store)
+        // is not scaled: "if (y > 1) phi.scale(y)"  hgaprec.cc:1355-1356
+        const double yy = (y > 1u) ? (double)y : 1.0;
+        const double scale = (act && ssum > 0.0) ? yy / ssum : 0.0;
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[t].x[v] = fma(x[t].x[v], scale, acc[t].x[v]);
+      }
+    }
+
+    // ---- reduce the 64/G group accumulators, write the row (or partial)
+    double *dst = (sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * ld
+                                  : a.S_own + (size_t)sg.row * ld;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        double r = acc[t].x[v];
+        if (G <= 32) r += __shfl_xor(r, 32, 64);
+        if (G <= 16) r += __shfl_xor(r, 16, 64);
+        if (G <= 8)  r += __shfl_xor(r, 8, 64);
+        if (G <= 4)  r += __shfl_xor(r, 4, 64);
+        acc[t].x[v] = r;
+      }
+      if (q == 0 && cok[t])
+        *reinterpret_cast<vecd<V> *>(dst + (size_t)(g + G * t) * V) = acc[t];
+    }
+  }
+}
+
+// long rows: S[row] = sum over its segments' partials, in segment order
+__global__ void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
+                                        const double *partial, double *S, uint32_t ld)
+{
+  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const LongRow lr = rows[r];
+    for (uint32_t c = threadIdx.x; c < ld; c += blockDim.x) {
+      double s = 0.0;
+      for (uint32_t p = 0; p < lr.nslots; ++p)
+        s += partial[(size_t)(lr.first_slot + p) * ld + c];
+      S[(size_t)lr.row * ld + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// digamma for x > 0: shift to x >= 10 with psi(x) = psi(x+N) - P'(x)/P(x),
+// P(x) = prod_{j<N}(x+j) (one division instead of N), then the asymptotic
+// series (A&S 6.3.18) through x^-14.  Stands where the reference calls
+// gsl_sf_psi (gpbase.hh:260).  |err| <~ 4e-15 abs on [1e-30, inf).
+// ---------------------------------------------------------------------
+__device__ __forceinline__ double digamma_pos(double x)
+{
+  double p = 1.0, dp = 0.0;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const bool sh = x < 10.0;
+    const double np = p * x, ndp = fma(dp, x, p);
+    p = sh ? np : p; dp = sh ? ndp : dp; x = sh ? x + 1.0 : x;
+  }
+  const double xi = 1.0 / x, x2 = xi * xi;
+  double s = 1.0 / 12.0;
+  s = fma(-x2, s, 691.0 / 32760.0);
+  s = fma(-x2, s, 1.0 / 132.0);
+  s = fma(-x2, s, 1.0 / 240.0);
+  s = fma(-x2, s, 1.0 / 252.0);
+  s = fma(-x2, s, 1.0 / 120.0);
+  s = fma(-x2, s, 1.0 / 12.0);
+  return log(x) - 0.5 * xi - x2 * s - dp / p;
+}
+
+// ---------------------------------------------------------------------
+// K2/K3 (+K4, K5, K7): row sweep.  One G-lane group per row, column
+// g + G*t in register slot t.  For every row (reference steps B/C, D, E/F of
+// hgaprec.cc:1370-1414; non-hier: 944-956, 1252-1268):
+//   shape = s_prior + S            (S = raw phi sums; written back as shape)
+//   rate  = prior_rate(row) + colsum_other[k]        k < K
+//           r_prior + n_other_total                   bias column
+//   E = shape/rate ; Elog = psi(shape) - log(rate) ; W = exp(Elog - rowmax)
+//   hier: xi/eta update  E_prior(row) = (s0 + K*s0) / (r0 + sum_k E[row,k])
+//   block partial column sums of E  (-> colsum kernel, fixed order)
+// ---------------------------------------------------------------------
+struct SweepArgs {
+  double       *S;          // [rows x ld] in: raw sums, out: shape
+  double       *E;          // [rows x ld]
+  double       *L;          // [rows x ld] Elog
+  double       *W;          // [rows x ld]
+  double       *prior_E;    // [rows] E[xi] / E[eta]: in old, out new (hier)
+  double       *prior_used; // [rows] value of prior_E used for this rate
+  double       *prior_rate; // [rows] rate of the xi/eta Gamma after update
+  const double *colsum_oth; // [ld]   sum over the other side's rows of E
+  double       *colsum_part;// [nblocks x ld]
+  uint32_t      rows, ld, K;
+  int32_t       bias_col;   // column holding this side's bias (-1: none)
+  int32_t       junk_col;   // column holding the other side's bias (-1: none)
+  double        bias_rate_add;  // n_other_total for the bias column
+  double        s_prior, r_prior;
+  uint32_t      hier;
+};
+
+template <int G, int R>
+__global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
+{
+  constexpr int NG = 64 / G;
+  __shared__ double red[4][64 * R];      // per-wave column partials
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = lane % G, q = lane / G;
+  const uint32_t ld = a.ld, K = a.K;
+  const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint32_t ngrp = (gridDim.x * blockDim.x) / G;
+
+  double csum[R], cso[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    csum[t] = 0.0;
+    const uint32_t c = g + G * t;
+    cso[t] = (c < K) ? a.colsum_oth[c] : 0.0;
+  }
+
+  for (uint32_t row = grp; row < a.rows; row += ngrp) {
+    const size_t base = (size_t)row * ld;
+    const double pr = a.hier ? a.prior_E[row] : a.r_prior;
+    double e[R], l[R];
+    double rmax = -1.0e308, rsum = 0.0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const uint32_t c = g + G * t;
+      e[t] = 0.0; l[t] = 0.0;
+      if (c < ld) {
+        const bool real = c < K, isb = (int32_t)c == a.bias_col;
+        const bool junk = (int32_t)c == a.junk_col;
+        if (real || isb) {
+          double sh = a.s_prior + a.S[base + c];
+          double rt = real ? pr + cso[t] : a.r_prior + a.bias_rate_add;
+          // GPBase::make_nonzero, gpbase.hh:27-44
+          sh = (sh > 0.0) ? sh : 1e-30;
+          rt = (rt > 0.0) ? rt : 1e-30;
+          e[t] = sh / rt;
+          l[t] = digamma_pos(sh) - log(rt);
+          a.S[base + c] = sh;
+          rmax = fmax(rmax, l[t]);
+          if (real) rsum += e[t];
+        } else {
+          a.S[base + c] = 0.0;
+          if (junk) rmax = fmax(rmax, 0.0);
+        }
+      }
+    }
+    rmax = group_max<G>(rmax);
+    rsum = group_sum<G>(rsum);
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const uint32_t c = g + G * t;
+      if (c < ld) {
+        const bool live = c < K || (int32_t)c == a.bias_col || (int32_t)c == a.junk_col;
+        a.E[base + c] = e[t];
+        a.L[base + c] = l[t];
+        a.W[base + c] = live ? exp(l[t] - rmax) : 0.0;
+        if (c < K) csum[t] += e[t];
+      }
+    }
+    if (a.hier && g == 0) {
+      // thetarate/betarate: gpbase.hh:877-889,912-925 via hgaprec.cc:1398-1414
+      const double sh = a.s_prior + (double)K * a.s_prior;
+      const double rt = a.r_prior + rsum;
+      a.prior_used[row] = pr;
+      a.prior_rate[row] = rt;
+      a.prior_E[row] = sh / rt;
+    }
+  }
+
+  // block partial column sums, fixed order: groups of a wave, then waves
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    double v = csum[t];
+    if (G <= 32) v += __shfl_xor(v, 32, 64);
+    if (G <= 16) v += __shfl_xor(v, 16, 64);
+    if (G <= 8)  v += __shfl_xor(v, 8, 64);
+    if (G <= 4)  v += __shfl_xor(v, 4, 64);
+    if (q == 0) red[wv][g + G * t] = v;
+  }
+  (void)NG;
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < ld; c += blockDim.x) {
+    double v = 0.0;
+    if (c < (uint32_t)(G * R)) v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    a.colsum_part[(size_t)blockIdx.x * ld + c] = (c < K) ? v : 0.0;
+  }
+}
+
+// out[c] = sum over blocks, in block order (deterministic)
+__global__ void colsum_finalize_kernel(const double *part, uint32_t nblocks,
+                                       uint32_t ld, double *out)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  double s = 0.0;
+  for (uint32_t b = 0; b < nblocks; ++b) s += part[(size_t)b * ld + c];
+  out[c] = s;
+}
+
+// plain column sums of E over rows (used once after hpf_set_state):
+// block partials in the same layout as the sweep's
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
+    uint32_t rows, uint32_t ld, uint32_t K, double *part)
+{
+  // thread c accumulates column c over this block's slice of rows
+  const uint32_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const uint32_t r0 = blockIdx.x * per;
+  const uint32_t r1 = (r0 + per < rows) ? r0 + per : rows;
+  for (uint32_t c = threadIdx.x; c < ld; c += blockDim.x) {
+    double s = 0.0;
+    if (c < K)
+      for (uint32_t r = r0; r < r1; ++r) s += E[(size_t)r * ld + c];
+    part[(size_t)blockIdx.x * ld + c] = s;
+  }
+}
+
+// W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
+__global__ void derive_w_kernel(const double *L, double *W, uint32_t rows,
+                                uint32_t ld, uint32_t K, int32_t bias_col,
+                                int32_t junk_col)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t row = wave; row < rows; row += nwaves) {
+    double m = -1.0e308;
+    for (uint32_t c = lane; c < ld; c += 64) {
+      const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
+      if (live) m = fmax(m, L[(size_t)row * ld + c]);
+    }
+    m = group_max<64>(m);
+    for (uint32_t c = lane; c < ld; c += 64) {
+      const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
+      W[(size_t)row * ld + c] = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// K6: held-out log-likelihood per pair (rating_likelihood_hier,
+// hgaprec.cc:1538-1560; rating_likelihood 1503-1536).  One 16-lane group
+// per pair; the per-pair values are summed on the host in the given order.
+// ---------------------------------------------------------------------
+struct LLArgs {
+  const uint32_t *u, *i;
+  const int32_t  *y;
+  uint64_t        cnt;
+  const double   *Et, *Eb;     // [n x ld], [m x ld]
+  const double   *logfact;     // [256]
+  double         *out;         // [cnt]
+  uint32_t        ld, K;
+  int32_t         ubias_col, ibias_col;   // -1 without -bias
+  uint32_t        binary;
+};
+
+__global__ __launch_bounds__(256) void heldout_ll_kernel(LLArgs a)
+{
+  constexpr int G = 16;
+  const int lane = threadIdx.x & 63, g = lane % G;
+  const uint64_t grp = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint64_t ngrp = ((uint64_t)gridDim.x * blockDim.x) / G;
+  for (uint64_t p0 = 0; p0 < a.cnt; p0 += ngrp) {
+    const uint64_t p = p0 + grp;
+    const bool ok = p < a.cnt;
+    const uint32_t u = ok ? a.u[p] : 0u, it = ok ? a.i[p] : 0u;
+    const double *et = a.Et + (size_t)u * a.ld, *eb = a.Eb + (size_t)it * a.ld;
+    double s = 0.0;
+    if (ok)
+      for (uint32_t c = g; c < a.K; c += G) s = fma(et[c], eb[c], s);
+    s = group_sum<G>(s);
+    if (ok && g == 0) {
+      if (a.ubias_col >= 0) s += et[a.ubias_col] + eb[a.ibias_col];
+      if (s < 1e-30) s = 1e-30;
+      const uint32_t y = (uint32_t)a.y[p] & 0xffu;       // yval_t wrap
+      double ll;
+      if (a.binary) ll = (y == 0) ? -s : log(1.0 - exp(-s));
+      else ll = (double)y * log(s) - s - a.logfact[y];
+      a.out[p] = ll;
+    }
+  }
+}
+
+// materialise the per-element rate matrix for export (htheta_rate.tsv):
+// rate[row,k] = prior_used[row] + colsum[k]   (gpbase.hh:163-173,218-223)
+__global__ void build_rate_kernel(const double *prior_used, const double *colsum,
+                                  uint32_t rows, uint32_t K, double *out)
+{
+  const size_t n = (size_t)rows * K;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x)
+    out[e] = prior_used[e / K] + colsum[e % K];
+}
+
+// single-column staging for the bias objects (host <-> padded layout)
+__global__ void column_scatter_kernel(const double *src, double *dst_col, uint32_t rows, uint32_t ld)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    dst_col[(size_t)r * ld] = src[r];
+}
+__global__ void column_gather_kernel(const double *src_col, double *dst, uint32_t rows, uint32_t ld)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    dst[r] = src_col[(size_t)r * ld];
+}
+
+}  // namespace hpf

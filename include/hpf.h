@@ -1,0 +1,168 @@
+/*
+ * hpf.h -- C-ABI of libhpf_hip.so: the MI355X (gfx950) device side of the
+ * hgaprec CAVI inner loop (hierarchical / Bayesian Poisson factorization).
+ *
+ * The reference (premgopalan/hgaprec) is one C++ executable with no plugin or
+ * FFI seam; this ABI is the seam a maintainer would cut where the inference
+ * driver (src/hgaprec.cc, class HGAPRec) meets the Gamma containers
+ * (src/gpbase.hh) and the ratings store (src/ratings.hh).  Each entry point
+ * names the reference code it replaces (file:line, relative to the reference's
+ * src/).  INTEGRATION.md shows the reference-side patch.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every host pointer and may free it
+ *    as soon as the call returns; the handle owns all device memory.
+ *  - every function returns HPF_OK (0) or a negative hpf_status and never
+ *    throws or aborts; hpf_last_error(h) gives the text of the last failure.
+ *  - one host thread per handle; distinct handles are independent.
+ *  - all real-valued state is fp64, like the reference (env.hh / gpbase.hh use
+ *    double throughout); ids are uint32, ratings uint8 (yval_t, env.hh:20).
+ *  - multi-GPU: one handle per rank holding a contiguous range of users (and
+ *    their nonzeros); item-side state is replicated.  The only exchange per
+ *    iteration is a sum-all-reduce of hpf_exchange_buffer() between
+ *    hpf_iterate_local() and hpf_iterate_global().
+ */
+#ifndef HPF_H
+#define HPF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPF_ABI_VERSION 1
+
+typedef struct hpf_handle hpf_handle;
+
+typedef enum {
+  HPF_OK = 0,
+  HPF_ERR_INVALID = -1,      /* bad argument / call order                    */
+  HPF_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime error   */
+  HPF_ERR_OOM = -3,          /* device or host allocation failed              */
+  HPF_ERR_HIP = -4,          /* a HIP call or kernel launch failed            */
+  HPF_ERR_UNSUPPORTED = -5,  /* e.g. K + 2*bias > HPF_MAX_COLUMNS             */
+  HPF_ERR_STATE = -6         /* state not initialised (no CSR / no E, Elog)   */
+} hpf_status;
+
+#define HPF_MAX_COLUMNS 512
+
+/* Gamma objects of the model (HGAPRec members, hgaprec.hh:94-112) x the four
+ * per-object arrays of gpbase.hh (shape_curr, rate_curr, expected_v,
+ * expected_logv).  Host layout is dense row-major doubles:
+ *   THETA_* : n_users x K   (htheta, or theta without -hier)
+ *   BETA_*  : n_items x K   (hbeta / beta)
+ *   XI_*    : n_users       (thetarate; -hier only)
+ *   ETA_*   : n_items       (betarate;  -hier only)
+ *   UBIAS_* : n_users       (thetabias; -bias only)
+ *   IBIAS_* : n_items       (betabias;  -bias only)
+ * Without -hier, THETA_RATE / BETA_RATE are K-vectors (GPMatrixGR::_rcurr,
+ * gpbase.hh:520). */
+typedef enum {
+  HPF_THETA_SHAPE = 0, HPF_THETA_RATE, HPF_THETA_E, HPF_THETA_ELOG,
+  HPF_BETA_SHAPE, HPF_BETA_RATE, HPF_BETA_E, HPF_BETA_ELOG,
+  HPF_XI_SHAPE, HPF_XI_RATE, HPF_XI_E, HPF_XI_ELOG,
+  HPF_ETA_SHAPE, HPF_ETA_RATE, HPF_ETA_E, HPF_ETA_ELOG,
+  HPF_UBIAS_SHAPE, HPF_UBIAS_RATE, HPF_UBIAS_E, HPF_UBIAS_ELOG,
+  HPF_IBIAS_SHAPE, HPF_IBIAS_RATE, HPF_IBIAS_E, HPF_IBIAS_ELOG,
+  HPF_NUM_STATE
+} hpf_state;
+
+typedef struct {
+  uint32_t struct_size;    /* sizeof(hpf_config), for ABI growth             */
+  uint32_t n_users;        /* users owned by THIS handle (its shard)         */
+  uint32_t n_items;        /* all items (replicated)                         */
+  uint32_t K;              /* factors (-k)                                   */
+  uint32_t hier;           /* -hier : vb_hier()  else vb() / vb_bias()       */
+  uint32_t bias;           /* -bias                                          */
+  uint32_t binary;         /* -binary-data (held-out likelihood form)        */
+  uint32_t n_users_total;  /* users over all ranks (item-bias rate 0.3 + n,  */
+                           /* hgaprec.cc:1393); 0 => n_users                 */
+  int32_t  device;         /* HIP device ordinal                             */
+  uint32_t n_ranks;        /* 1 => hpf_iterate() needs no exchange           */
+  uint32_t rank;
+  uint32_t reserved0;
+  void    *stream;         /* hipStream_t to run on, NULL => own stream      */
+  double   s_prior;        /* 0.3 (hgaprec.cc:13-20 hard-codes both)         */
+  double   r_prior;        /* 0.3                                            */
+} hpf_config;
+
+/* per-kernel device time of the most recent iteration, milliseconds, from
+ * hipEvents recorded on the handle's stream */
+typedef struct {
+  float phi_user_ms;    /* K1a: user-major phi pass (theta shape sums)       */
+  float phi_item_ms;    /* K1b: item-major phi pass (beta shape sums)        */
+  float sweep_user_ms;  /* K2 + K4(xi) + K5(user bias) + K7                  */
+  float sweep_item_ms;  /* K3 + K4(eta) + K5(item bias) + K7                 */
+  float iteration_ms;   /* first launch -> last launch of the iteration      */
+  uint32_t iterations;  /* iterations executed so far                        */
+} hpf_timing;
+
+int  hpf_abi_version(void);
+const char *hpf_strerror(int status);
+const char *hpf_last_error(const hpf_handle *h);
+
+/* replaces: HGAPRec::HGAPRec allocation of the 8 Gamma objects
+ * (hgaprec.cc:8-33) */
+int  hpf_create(const hpf_config *cfg, hpf_handle **out);
+void hpf_destroy(hpf_handle *h);
+
+/* replaces: the per-user adjacency + rating maps built by
+ * Ratings::read_generic (ratings.cc:63-119) and walked by
+ * Ratings::get_movies / Ratings::r (ratings.hh:175-181,153-165).
+ * CSR over this handle's users in the reference's visiting order; col = item
+ * seq id; val = rating as stored by the reference (uint8, already wrapped,
+ * last duplicate wins), NULL => every rating is 1 (-binary-data).
+ * Host pointers.  Builds the item-major (CSC) view and work lists on device. */
+int  hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col,
+                    const uint8_t *val);
+
+/* replaces: the result of HGAPRec::initialize (hgaprec.cc:153-204) -- the host
+ * draws the MT19937 stream and hands over E / Elog (and shapes, for export).
+ * count must equal the element count of that array. */
+int  hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t count);
+/* replaces: reads of shape_curr()/rate_curr()/expected_v()/expected_logv()
+ * by save_model (hgaprec.cc:2137-2158) */
+int  hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count);
+
+/* replaces: n_iters passes of steps A-F of HGAPRec::vb_hier
+ * (hgaprec.cc:1340-1414), or of vb (927-956) / vb_bias (1226-1272) without
+ * -hier.  n_ranks must be 1.  Asynchronous on the handle's stream. */
+int  hpf_iterate(hpf_handle *h, int n_iters);
+
+/* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,
+ * E) and the local partial sums ... */
+int  hpf_iterate_local(hpf_handle *h);
+/* ... the caller sum-all-reduces this device buffer of `count` doubles in
+ * place (RCCL ncclAllReduce(ncclDouble, ncclSum) / torch.distributed) on the
+ * handle's stream ... */
+int  hpf_exchange_buffer(hpf_handle *h, void **device_ptr, size_t *count);
+/* optional: make the handle use caller-owned device memory (>= count doubles,
+ * 16-byte aligned) as the exchange buffer; call before hpf_upload_csr */
+int  hpf_bind_exchange_buffer(hpf_handle *h, void *device_ptr, size_t count);
+/* ... then the replicated item sweep (C, D-item, F) on every rank. */
+int  hpf_iterate_global(hpf_handle *h);
+
+/* replaces: the per-pair loop of HGAPRec::compute_likelihood
+ * (hgaprec.cc:1455-1465) with rating_likelihood_hier / rating_likelihood
+ * (1538-1560 / 1503-1536).  u is a LOCAL user index, y the int stored in the
+ * CountMap (wrapped to uint8 like `yval_t r = i->second`).  Pairs are summed
+ * in the order given (the caller passes them sorted by (user, item) like the
+ * std::map).  Synchronous. */
+int  hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i,
+                    const int32_t *y, size_t cnt, double *sum_out,
+                    uint64_t *cnt_out);
+
+int  hpf_synchronize(hpf_handle *h);
+int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
+
+/* algorithmic bytes (SURVEY.md section 8d / DESIGN.md) moved by one launch of
+ * the two phi passes and of the row sweeps for the uploaded matrix */
+int  hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item,
+                           uint64_t *rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPF_H */

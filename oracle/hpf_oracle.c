@@ -1,0 +1,885 @@
+/*
+ * hpf_oracle.c -- TEST INFRASTRUCTURE ONLY (see hpf_oracle.h for the parity
+ * status: "parity unpinned" end-to-end, component pins listed there).
+ *
+ * Plain-C, single-thread, fp64 restatement of the reference algorithm.  It
+ * keeps the reference's own data flow (shape/rate "curr" and "next" buffers,
+ * swap + reset to prior, sequential log-add-exp, serial summation order) so
+ * that its results are what the reference binary computes up to the
+ * last-ulp differences between GSL's psi and the psi below.  Every function
+ * cites the reference file:line it follows (paths relative to
+ * /root/reference/src).
+ */
+#define _GNU_SOURCE
+#include "hpf_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <assert.h>
+
+/* ------------------------------------------------------------------ */
+/* MT19937: GSL 2.x rng/mt.c (gsl_rng_mt19937), the generator behind    */
+/* gsl_rng_default (hgaprec.cc:34-38).  Published algorithm: Matsumoto  */
+/* & Nishimura 1998, 2002 init_genrand seeding; GSL maps seed 0 -> 4357.*/
+/* ------------------------------------------------------------------ */
+void orc_rng_seed(orc_rng *r, unsigned long s)
+{
+  if (s == 0) s = 4357;
+  r->mt[0] = (uint32_t)(s & 0xffffffffUL);
+  for (int i = 1; i < 624; ++i) {
+    uint32_t p = r->mt[i - 1];
+    r->mt[i] = (uint32_t)(1812433253UL * (p ^ (p >> 30)) + (unsigned long)i);
+  }
+  r->mti = 624;
+}
+
+uint32_t orc_rng_u32(orc_rng *r)
+{
+  uint32_t *mt = r->mt;
+  if (r->mti >= 624) {
+    int kk;
+    for (kk = 0; kk < 624 - 397; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+      mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+    }
+    for (; kk < 623; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+      mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+    }
+    uint32_t y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+    r->mti = 0;
+  }
+  uint32_t k = mt[r->mti++];
+  k ^= (k >> 11);
+  k ^= (k << 7) & 0x9d2c5680U;
+  k ^= (k << 15) & 0xefc60000U;
+  k ^= (k >> 18);
+  return k;
+}
+
+/* gsl_rng_uniform for mt19937 = mt_get_double = u32 / 2^32 */
+double orc_rng_uniform(orc_rng *r) { return orc_rng_u32(r) / 4294967296.0; }
+
+/* gsl_rng_uniform_int (rng/rng.c): range = max-min = 0xffffffff */
+unsigned long orc_rng_uniform_int(orc_rng *r, unsigned long n)
+{
+  unsigned long scale = 0xffffffffUL / n, k;
+  do { k = orc_rng_u32(r) / scale; } while (k >= n);
+  return k;
+}
+
+/* ------------------------------------------------------------------ */
+/* digamma, x > 0.  The reference calls gsl_sf_psi (gpbase.hh:260,336)  */
+/* -- GSL is a third-party dependency absent here and not version-      */
+/* pinned by the reference (configure.ac only probes -lgsl).  psi is a   */
+/* mathematical function; GSL documents ~2 eps accuracy.  This          */
+/* evaluates it in long double: upward recurrence to x >= 20, then the  */
+/* Stirling/Bernoulli asymptotic series (A&S 6.3.18), and rounds once.  */
+/* ------------------------------------------------------------------ */
+double orc_psi(double xd)
+{
+  long double x = xd, acc = 0.0L;
+  while (x < 20.0L) { acc -= 1.0L / x; x += 1.0L; }
+  long double xi = 1.0L / x, x2 = xi * xi;
+  /* B_2n / (2n): 1/12, 1/120, 1/252, 1/240, 1/132, 691/32760, 1/12,
+     3617/8160, 43867/14364 */
+  long double s = x2 * (1.0L / 12 - x2 * (1.0L / 120 - x2 * (1.0L / 252 -
+                  x2 * (1.0L / 240 - x2 * (1.0L / 132 - x2 * (691.0L / 32760 -
+                  x2 * (1.0L / 12 - x2 * (3617.0L / 8160 -
+                  x2 * (43867.0L / 14364)))))))));
+  return (double)(acc + logl(x) - 0.5L * xi - s);
+}
+
+/* ------------------------------------------------------------------ */
+/* matrix.hh:367-381  D1Array<T>::logsum -- sequential log-add-exp     */
+/* ------------------------------------------------------------------ */
+double orc_logsum(const double *d, uint32_t n)
+{
+  assert(n > 0);
+  if (n == 1) return d[0];
+  double r = d[0];
+  for (uint32_t i = 1; i < n; ++i) {
+    if (d[i] < r) r = r + log(1 + exp(d[i] - r));
+    else          r = d[i] + log(1 + exp(r - d[i]));
+  }
+  return r;
+}
+
+/* matrix.hh:383-389 */
+void orc_lognormalize(double *d, uint32_t n)
+{
+  double s = orc_logsum(d, n);
+  for (uint32_t i = 0; i < n; ++i) d[i] = exp(d[i] - s);
+}
+
+/* ------------------------------------------------------------------ */
+/* Ratings store: ratings.cc:63-119, ratings.hh:117-165,191-197        */
+/* ------------------------------------------------------------------ */
+typedef struct { uint32_t key, val; } kv32;
+
+/* tiny open-addressing id -> seq map (replaces std::map lookups; order of
+   insertion, not of keys, defines seq ids -- same as IDMap usage) */
+typedef struct { kv32 *t; uint32_t cap, cnt; uint8_t *used; } idmap;
+
+static void idmap_init(idmap *h, uint32_t cap0)
+{
+  h->cap = 16; while (h->cap < cap0 * 2u) h->cap <<= 1;
+  h->cnt = 0;
+  h->t = (kv32 *)calloc(h->cap, sizeof(kv32));
+  h->used = (uint8_t *)calloc(h->cap, 1);
+}
+static void idmap_free(idmap *h) { free(h->t); free(h->used); }
+static uint32_t idmap_hash(uint32_t k) { k *= 2654435761u; return k ^ (k >> 15); }
+static int idmap_find(const idmap *h, uint32_t key, uint32_t *val)
+{
+  uint32_t i = idmap_hash(key) & (h->cap - 1);
+  while (h->used[i]) {
+    if (h->t[i].key == key) { *val = h->t[i].val; return 1; }
+    i = (i + 1) & (h->cap - 1);
+  }
+  return 0;
+}
+static void idmap_put(idmap *h, uint32_t key, uint32_t val);
+static void idmap_grow(idmap *h)
+{
+  idmap o = *h;
+  h->cap = o.cap * 2; h->cnt = 0;
+  h->t = (kv32 *)calloc(h->cap, sizeof(kv32));
+  h->used = (uint8_t *)calloc(h->cap, 1);
+  for (uint32_t i = 0; i < o.cap; ++i)
+    if (o.used[i]) idmap_put(h, o.t[i].key, o.t[i].val);
+  idmap_free(&o);
+}
+static void idmap_put(idmap *h, uint32_t key, uint32_t val)
+{
+  if ((h->cnt + 1) * 2u > h->cap) idmap_grow(h);
+  uint32_t i = idmap_hash(key) & (h->cap - 1);
+  while (h->used[i]) {
+    if (h->t[i].key == key) { h->t[i].val = val; return; }
+    i = (i + 1) & (h->cap - 1);
+  }
+  h->used[i] = 1; h->t[i].key = key; h->t[i].val = val; h->cnt++;
+}
+
+typedef struct { uint32_t u, i; int32_t y; uint64_t ord; } triple;
+
+struct orc_ratings {
+  uint32_t cap_n, cap_m;   /* Env::n / Env::m while reading train */
+  int binary; uint32_t thr;
+  idmap user2seq, item2seq;
+  uint32_t *seq2user, *seq2item;
+  uint32_t nusers, nitems;
+  /* training triples in file order (seq ids, raw rating) */
+  triple *tr; uint64_t ntr, captr;
+  int finalized;
+  int64_t *rowptr; uint32_t *col; uint8_t *val;
+  /* heldout maps */
+  triple *ho[2]; uint64_t nho[2], capho[2];
+  uint32_t *ho_u[2], *ho_i[2]; int32_t *ho_y[2];
+};
+
+orc_ratings *orc_ratings_new(uint32_t cap_n, uint32_t cap_m, int binary,
+                             uint32_t thr)
+{
+  orc_ratings *r = (orc_ratings *)calloc(1, sizeof(*r));
+  r->cap_n = cap_n; r->cap_m = cap_m; r->binary = binary; r->thr = thr;
+  idmap_init(&r->user2seq, 1024); idmap_init(&r->item2seq, 1024);
+  r->seq2user = (uint32_t *)malloc(sizeof(uint32_t) * (cap_n ? cap_n : 1));
+  r->seq2item = (uint32_t *)malloc(sizeof(uint32_t) * (cap_m ? cap_m : 1));
+  return r;
+}
+
+void orc_ratings_free(orc_ratings *r)
+{
+  if (!r) return;
+  idmap_free(&r->user2seq); idmap_free(&r->item2seq);
+  free(r->seq2user); free(r->seq2item); free(r->tr);
+  free(r->rowptr); free(r->col); free(r->val);
+  for (int w = 0; w < 2; ++w) {
+    free(r->ho[w]); free(r->ho_u[w]); free(r->ho_i[w]); free(r->ho_y[w]);
+  }
+  free(r);
+}
+
+/* ratings.hh:191-197 */
+static uint32_t input_rating_class(const orc_ratings *r, uint32_t v)
+{
+  if (!r->binary) return v;
+  return v >= r->thr ? 1 : 0;
+}
+
+static int cmp_row_then_order(const void *a, const void *b)
+{
+  const triple *x = (const triple *)a, *y = (const triple *)b;
+  if (x->u != y->u) return x->u < y->u ? -1 : 1;
+  return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+static int cmp_pair_then_order(const void *a, const void *b)
+{
+  const triple *x = (const triple *)a, *y = (const triple *)b;
+  if (x->u != y->u) return x->u < y->u ? -1 : 1;
+  if (x->i != y->i) return x->i < y->i ? -1 : 1;
+  return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+
+/* ratings.cc:63-119.  heldout < 0: training pass (cmap == NULL there) */
+static int read_generic(orc_ratings *r, FILE *f, int heldout)
+{
+  uint32_t mid = 0, uid = 0, rating = 0;
+  /* capacity seen by this pass: ratings.cc:35-36 shrinks env.n/env.m to the
+     registered counts after the training pass */
+  uint32_t cap_n = heldout < 0 ? r->cap_n : r->nusers;
+  uint32_t cap_m = heldout < 0 ? r->cap_m : r->nitems;
+  while (!feof(f)) {
+    int got = fscanf(f, "%u\t%u\t%u\n", &uid, &mid, &rating);
+    if (got < 0) {                       /* ratings.cc:71-75: exit(-1) */
+      fprintf(stderr, "error: unexpected lines in file\n");
+      return -1;
+    }
+    if (got != 3) {
+      /* the reference would spin forever on a non-numeric token (nothing is
+         consumed); the oracle reports it instead */
+      fprintf(stderr, "error: malformed line in ratings file\n");
+      return -1;
+    }
+    uint32_t n = 0, m = 0;
+    int hasu = idmap_find(&r->user2seq, uid, &n);
+    int hasm = idmap_find(&r->item2seq, mid, &m);
+    if ((!hasu && r->nusers >= cap_n) || (!hasm && r->nitems >= cap_m))
+      continue;
+    if (input_rating_class(r, rating) == 0) continue;
+    if (!hasu) {                         /* ratings.hh:117-133 add_user */
+      n = r->nusers; idmap_put(&r->user2seq, uid, n);
+      r->seq2user[r->nusers++] = uid;
+    }
+    if (!hasm) {                         /* ratings.hh:135-151 add_movie */
+      m = r->nitems; idmap_put(&r->item2seq, mid, m);
+      r->seq2item[r->nitems++] = mid;
+    }
+    triple t; t.u = n; t.i = m; t.y = (int32_t)rating; t.ord = 0;
+    if (heldout < 0) {
+      if (r->ntr == r->captr) {
+        r->captr = r->captr ? r->captr * 2 : 4096;
+        r->tr = (triple *)realloc(r->tr, r->captr * sizeof(triple));
+      }
+      t.ord = r->ntr; r->tr[r->ntr++] = t;
+    } else {
+      int w = heldout;
+      if (r->nho[w] == r->capho[w]) {
+        r->capho[w] = r->capho[w] ? r->capho[w] * 2 : 1024;
+        r->ho[w] = (triple *)realloc(r->ho[w], r->capho[w] * sizeof(triple));
+      }
+      t.ord = r->nho[w]; t.y = r->binary ? 1 : (int32_t)rating;
+      r->ho[w][r->nho[w]++] = t;
+    }
+  }
+  return 0;
+}
+
+static void finalize_train(orc_ratings *r)
+{
+  /* per-user item vector keeps file order (ratings.cc:105 push_back); the
+     rating looked up at sweep time is the LAST value written to the per-user
+     std::map<item, uint8_t> (ratings.cc:96-103, ratings.hh:153-165) */
+  uint64_t nnz = r->ntr;
+  triple *s = (triple *)malloc((nnz ? nnz : 1) * sizeof(triple));
+  memcpy(s, r->tr, nnz * sizeof(triple));
+  qsort(s, nnz, sizeof(triple), cmp_pair_then_order);
+  /* last duplicate wins; stored as yval_t = uint8_t (env.hh:20) */
+  uint8_t *lastval = (uint8_t *)malloc(nnz ? nnz : 1);
+  for (uint64_t a = 0; a < nnz;) {
+    uint64_t b = a;
+    while (b + 1 < nnz && s[b + 1].u == s[a].u && s[b + 1].i == s[a].i) ++b;
+    uint8_t v = r->binary ? 1 : (uint8_t)(uint32_t)s[b].y;
+    for (uint64_t c = a; c <= b; ++c) lastval[s[c].ord] = v;
+    a = b + 1;
+  }
+  memcpy(s, r->tr, nnz * sizeof(triple));
+  qsort(s, nnz, sizeof(triple), cmp_row_then_order);
+  r->rowptr = (int64_t *)calloc((size_t)r->nusers + 1, sizeof(int64_t));
+  r->col = (uint32_t *)malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+  r->val = (uint8_t *)malloc(nnz ? nnz : 1);
+  for (uint64_t a = 0; a < nnz; ++a) {
+    r->rowptr[s[a].u + 1]++;
+    r->col[a] = s[a].i;
+    r->val[a] = lastval[s[a].ord];
+  }
+  for (uint32_t u = 0; u < r->nusers; ++u) r->rowptr[u + 1] += r->rowptr[u];
+  free(s); free(lastval);
+  r->finalized = 1;
+}
+
+int orc_ratings_read_train(orc_ratings *r, const char *path)
+{
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int rc = read_generic(r, f, -1);
+  fclose(f);
+  if (rc == 0) finalize_train(r);
+  return rc;
+}
+
+int orc_ratings_read_heldout(orc_ratings *r, const char *path, int w)
+{
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int rc = read_generic(r, f, w);
+  fclose(f);
+  if (rc) return rc;
+  /* std::map<Rating,int>: unique keys, last assignment wins, sorted */
+  uint64_t n = r->nho[w];
+  qsort(r->ho[w], n, sizeof(triple), cmp_pair_then_order);
+  r->ho_u[w] = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  r->ho_i[w] = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  r->ho_y[w] = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+  uint64_t o = 0;
+  for (uint64_t a = 0; a < n;) {
+    uint64_t b = a;
+    while (b + 1 < n && r->ho[w][b + 1].u == r->ho[w][a].u &&
+           r->ho[w][b + 1].i == r->ho[w][a].i) ++b;
+    r->ho_u[w][o] = r->ho[w][b].u; r->ho_i[w][o] = r->ho[w][b].i;
+    r->ho_y[w][o] = r->ho[w][b].y; ++o;
+    a = b + 1;
+  }
+  r->nho[w] = o;
+  return 0;
+}
+
+uint32_t orc_ratings_n(const orc_ratings *r) { return r->nusers; }
+uint32_t orc_ratings_m(const orc_ratings *r) { return r->nitems; }
+uint64_t orc_ratings_nnz(const orc_ratings *r) { return r->ntr; }
+const int64_t  *orc_ratings_rowptr(const orc_ratings *r) { return r->rowptr; }
+const uint32_t *orc_ratings_col(const orc_ratings *r) { return r->col; }
+const uint8_t  *orc_ratings_val(const orc_ratings *r) { return r->val; }
+const uint32_t *orc_ratings_seq2user(const orc_ratings *r) { return r->seq2user; }
+const uint32_t *orc_ratings_seq2item(const orc_ratings *r) { return r->seq2item; }
+uint64_t orc_ratings_heldout_count(const orc_ratings *r, int w) { return r->nho[w]; }
+const uint32_t *orc_ratings_heldout_u(const orc_ratings *r, int w) { return r->ho_u[w]; }
+const uint32_t *orc_ratings_heldout_i(const orc_ratings *r, int w) { return r->ho_i[w]; }
+const int32_t  *orc_ratings_heldout_y(const orc_ratings *r, int w) { return r->ho_y[w]; }
+
+/* ratings.cc:217-271: seq, id, degree, sum of (uint8) ratings */
+int orc_ratings_write_marginals(const orc_ratings *r, const char *byusers,
+                                const char *byitems)
+{
+  FILE *f = fopen(byusers, "w");
+  if (!f) return -1;
+  for (uint32_t n = 0; n < r->nusers; ++n) {
+    int64_t a = r->rowptr[n], b = r->rowptr[n + 1];
+    if (a == b) continue;
+    uint32_t t = 0;
+    for (int64_t j = a; j < b; ++j) t += r->val[j];
+    fprintf(f, "%d\t%d\t%d\t%d\n", n, r->seq2user[n], (int)(b - a), t);
+  }
+  fclose(f);
+  uint32_t *deg = (uint32_t *)calloc(r->nitems ? r->nitems : 1, sizeof(uint32_t));
+  uint32_t *sum = (uint32_t *)calloc(r->nitems ? r->nitems : 1, sizeof(uint32_t));
+  for (uint64_t j = 0; j < r->ntr; ++j) { deg[r->col[j]]++; sum[r->col[j]] += r->val[j]; }
+  f = fopen(byitems, "w");
+  if (!f) { free(deg); free(sum); return -1; }
+  for (uint32_t i = 0; i < r->nitems; ++i) {
+    if (!deg[i]) continue;
+    fprintf(f, "%d\t%d\t%d\t%d\n", i, r->seq2item[i], deg[i], sum[i]);
+  }
+  fclose(f); free(deg); free(sum);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Gamma containers: gpbase.hh                                          */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  uint32_t n, k;       /* k == 1 for GPArray and the bias matrices */
+  int global_rate;     /* GPMatrixGR: rate is a k-vector           */
+  double sprior, rprior;
+  double *scurr, *snext, *rcurr, *rnext, *Ev, *Elogv;
+  size_t rsize;
+} gp;
+
+static void gp_set_to_prior(gp *g)   /* gpbase.hh:149-154,527-532,863-868 */
+{
+  size_t ns = (size_t)g->n * g->k;
+  for (size_t a = 0; a < ns; ++a) g->snext[a] = g->sprior;
+  for (size_t a = 0; a < g->rsize; ++a) g->rnext[a] = g->rprior;
+}
+
+static void gp_init(gp *g, uint32_t n, uint32_t k, int global_rate)
+{
+  g->n = n; g->k = k; g->global_rate = global_rate;
+  g->sprior = 0.3; g->rprior = 0.3;      /* hgaprec.cc:13-20: literal 0.3 */
+  size_t ns = (size_t)n * k; if (!ns) ns = 1;
+  g->rsize = global_rate ? k : (size_t)n * k;
+  size_t nr = g->rsize ? g->rsize : 1;
+  g->scurr = (double *)calloc(ns, 8); g->snext = (double *)calloc(ns, 8);
+  g->rcurr = (double *)calloc(nr, 8); g->rnext = (double *)calloc(nr, 8);
+  g->Ev = (double *)calloc(ns, 8); g->Elogv = (double *)calloc(ns, 8);
+}
+static void gp_free(gp *g)
+{
+  free(g->scurr); free(g->snext); free(g->rcurr); free(g->rnext);
+  free(g->Ev); free(g->Elogv);
+}
+
+/* gpbase.hh:27-44 */
+static void make_nonzero(double av, double bv, double *a, double *b)
+{
+  assert(av >= 0 && bv >= 0);
+  *b = !(bv > .0) ? 1e-30 : bv;
+  *a = !(av > .0) ? 1e-30 : av;
+}
+
+static void gp_swap(gp *g)           /* gpbase.hh:240-246,571-577,897-903 */
+{
+  double *t = g->scurr; g->scurr = g->snext; g->snext = t;
+  t = g->rcurr; g->rcurr = g->rnext; g->rnext = t;
+  gp_set_to_prior(g);
+}
+
+static void gp_compute_expectations(gp *g) /* gpbase.hh:248-262,579-598,912-925 */
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t j = 0; j < g->k; ++j) {
+      size_t e = (size_t)i * g->k + j;
+      double a, b;
+      make_nonzero(g->scurr[e], g->global_rate ? g->rcurr[j] : g->rcurr[e], &a, &b);
+      g->Ev[e] = a / b;
+      g->Elogv[e] = orc_psi(a) - log(b);
+    }
+}
+
+/* GPMatrix::initialize gpbase.hh:292-308 ; GPMatrixGR::initialize 651-663 */
+static void gp_initialize(gp *g, orc_rng *r)
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k)
+      g->scurr[(size_t)i * g->k + k] = g->sprior + 0.01 * orc_rng_uniform(r);
+  if (g->global_rate) {
+    for (uint32_t k = 0; k < g->k; ++k)
+      g->rcurr[k] = g->rprior + 0.1 * orc_rng_uniform(r);
+  } else {
+    /* the K draws always happen, even for n == 0 the reference would write
+       bd[0][k]; n >= 1 in every use */
+    double *b0 = (double *)malloc(sizeof(double) * (g->k ? g->k : 1));
+    for (uint32_t k = 0; k < g->k; ++k)
+      b0[k] = g->rprior + 0.1 * orc_rng_uniform(r);
+    for (uint32_t i = 0; i < g->n; ++i)
+      for (uint32_t k = 0; k < g->k; ++k)
+        g->rcurr[(size_t)i * g->k + k] = b0[k];
+    free(b0);
+  }
+  gp_set_to_prior(g);
+}
+
+/* GPMatrix::initialize2 gpbase.hh:310-322 ; GPArray::initialize2 939-949 */
+static void gp_initialize2(gp *g, double v, orc_rng *r)
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) {
+      size_t e = (size_t)i * g->k + k;
+      g->scurr[e] = g->sprior + 0.01 * orc_rng_uniform(r);
+      g->rcurr[e] = g->rprior + v;
+    }
+  gp_set_to_prior(g);
+}
+
+/* GPMatrix::initialize_exp gpbase.hh:324-340 ; GPMatrixGR 700-715 */
+static void gp_initialize_exp(gp *g, orc_rng *r)
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) {
+      size_t e = (size_t)i * g->k + k;
+      double b = g->rprior + 0.1 * orc_rng_uniform(r);
+      g->Ev[e] = g->scurr[e] / b;
+      g->Elogv[e] = orc_psi(g->scurr[e]) - log(b);
+    }
+  gp_set_to_prior(g);
+}
+
+/* sum_rows gpbase.hh:264-271 */
+static void gp_sum_rows(const gp *g, double *v)
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) v[k] += g->Ev[(size_t)i * g->k + k];
+}
+/* sum_cols gpbase.hh:273-280 */
+static void gp_sum_cols(const gp *g, double *v)
+{
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) v[i] += g->Ev[(size_t)i * g->k + k];
+}
+
+/* ------------------------------------------------------------------ */
+struct orc_model {
+  uint32_t n, m, K; int hier, bias, binary;
+  const int64_t *rowptr; const uint32_t *col; const uint8_t *val;
+  gp theta, beta;          /* htheta/hbeta (hier) or theta/beta (GR) */
+  gp xi, eta;              /* thetarate / betarate (hier only)       */
+  gp ubias, ibias;         /* thetabias / betabias                   */
+  orc_rng rng;
+  double *phi, *tmpK, *tmpN;
+};
+
+orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
+                         int binary)
+{
+  orc_model *M = (orc_model *)calloc(1, sizeof(*M));
+  M->n = n; M->m = m; M->K = K; M->hier = hier; M->bias = bias; M->binary = binary;
+  gp_init(&M->theta, n, K, !hier);
+  gp_init(&M->beta, m, K, !hier);
+  gp_init(&M->xi, n, 1, 0);
+  gp_init(&M->eta, m, 1, 0);
+  gp_init(&M->ubias, n, 1, 0);
+  gp_init(&M->ibias, m, 1, 0);
+  M->phi = (double *)calloc((size_t)K + 2, 8);
+  M->tmpK = (double *)calloc((size_t)K + 2, 8);
+  M->tmpN = (double *)calloc((size_t)(n > m ? n : m) + 1, 8);
+  orc_rng_seed(&M->rng, 0);
+  return M;
+}
+
+void orc_model_free(orc_model *M)
+{
+  if (!M) return;
+  gp_free(&M->theta); gp_free(&M->beta); gp_free(&M->xi); gp_free(&M->eta);
+  gp_free(&M->ubias); gp_free(&M->ibias);
+  free(M->phi); free(M->tmpK); free(M->tmpN); free(M);
+}
+
+void orc_model_set_csr(orc_model *M, const int64_t *rowptr, const uint32_t *col,
+                       const uint8_t *val)
+{ M->rowptr = rowptr; M->col = col; M->val = val; }
+
+orc_rng *orc_model_rng(orc_model *M) { return &M->rng; }
+
+/* hgaprec.cc:34-38 (seed) and 153-204 (initialize) */
+void orc_model_initialize(orc_model *M, double seed)
+{
+  /* gsl_rng_alloc seeds with gsl_rng_default_seed = 0 (-> 4357); then
+     if (_env.seed) gsl_rng_set(_r, _env.seed)  [double -> unsigned long] */
+  orc_rng_seed(&M->rng, 0);
+  if (seed) orc_rng_seed(&M->rng, (unsigned long)seed);
+  orc_rng *r = &M->rng;
+  if (!M->hier) {
+    gp_initialize(&M->beta, r);
+    gp_initialize(&M->theta, r);
+    gp_initialize_exp(&M->beta, r);
+    gp_initialize_exp(&M->theta, r);
+  } else {
+    gp_initialize2(&M->xi, (double)M->K, r);  gp_compute_expectations(&M->xi);
+    gp_initialize2(&M->eta, (double)M->K, r); gp_compute_expectations(&M->eta);
+    gp_initialize(&M->beta, r);  gp_initialize_exp(&M->beta, r);
+    gp_initialize(&M->theta, r); gp_initialize_exp(&M->theta, r);
+  }
+  if (M->bias) {
+    gp_initialize2(&M->ubias, (double)M->m, r); gp_compute_expectations(&M->ubias);
+    gp_initialize2(&M->ibias, (double)M->n, r); gp_compute_expectations(&M->ibias);
+  }
+}
+
+/* step A: hgaprec.cc:1340-1366 (hier), 928-942 (vb), 1227-1248 (vb_bias);
+   get_phi hgaprec.cc:206-239 */
+static void sweep_nonzeros(orc_model *M)
+{
+  const uint32_t K = M->K, x = M->bias ? K + 2 : K;
+  double *phi = M->phi;
+  for (uint32_t n = 0; n < M->n; ++n) {
+    const double *elt = M->theta.Elogv + (size_t)n * K;
+    for (int64_t j = M->rowptr[n]; j < M->rowptr[n + 1]; ++j) {
+      uint32_t m = M->col[j];
+      uint8_t y = M->val ? M->val[j] : 1;
+      const double *elb = M->beta.Elogv + (size_t)m * K;
+      for (uint32_t k = 0; k < K; ++k) phi[k] = elt[k] + elb[k];
+      if (M->bias) { phi[K] = M->ubias.Elogv[n]; phi[K + 1] = M->ibias.Elogv[m]; }
+      orc_lognormalize(phi, x);
+      if (y > 1)
+        for (uint32_t k = 0; k < x; ++k) phi[k] *= y;   /* matrix.hh:399-406 */
+      /* add_slice adds only the first K entries (matrix.hh:1060-1067) */
+      double *st = M->theta.snext + (size_t)n * K, *sb = M->beta.snext + (size_t)m * K;
+      for (uint32_t k = 0; k < K; ++k) st[k] += phi[k];
+      for (uint32_t k = 0; k < K; ++k) sb[k] += phi[k];
+      if (M->bias) { M->ubias.snext[n] += phi[K]; M->ibias.snext[m] += phi[K + 1]; }
+    }
+  }
+}
+
+static void bias_sweeps(orc_model *M)   /* hgaprec.cc:1388-1396 / 1262-1268 */
+{
+  for (uint32_t i = 0; i < M->n; ++i) M->ubias.rnext[i] += M->m; /* gpbase.hh:225-231 */
+  gp_swap(&M->ubias); gp_compute_expectations(&M->ubias);
+  for (uint32_t i = 0; i < M->m; ++i) M->ibias.rnext[i] += M->n;
+  gp_swap(&M->ibias); gp_compute_expectations(&M->ibias);
+}
+
+static void iterate_hier(orc_model *M)  /* hgaprec.cc:1340-1414 */
+{
+  const uint32_t K = M->K;
+  sweep_nonzeros(M);
+  /* B: hgaprec.cc:1370-1378 */
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->beta, M->tmpK);
+  for (uint32_t n = 0; n < M->n; ++n)            /* set_prior_rate gpbase.hh:163-173 */
+    for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] = M->xi.Ev[n];
+  for (uint32_t n = 0; n < M->n; ++n)            /* update_rate_next gpbase.hh:218-223 */
+    for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] += M->tmpK[k];
+  gp_swap(&M->theta); gp_compute_expectations(&M->theta);
+  /* C: hgaprec.cc:1380-1386 */
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->theta, M->tmpK);
+  for (uint32_t i = 0; i < M->m; ++i)
+    for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] = M->eta.Ev[i];
+  for (uint32_t i = 0; i < M->m; ++i)
+    for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] += M->tmpK[k];
+  gp_swap(&M->beta); gp_compute_expectations(&M->beta);
+  /* D */
+  if (M->bias) bias_sweeps(M);
+  /* E: hgaprec.cc:1398-1405 */
+  memset(M->tmpN, 0, sizeof(double) * M->n);
+  gp_sum_cols(&M->theta, M->tmpN);
+  { double v = K * M->xi.sprior;                  /* _k * _thetarate.sprior() */
+    for (uint32_t n = 0; n < M->n; ++n) M->xi.snext[n] += v;      /* gpbase.hh:877-882 */
+    for (uint32_t n = 0; n < M->n; ++n) M->xi.rnext[n] += M->tmpN[n]; }
+  gp_swap(&M->xi); gp_compute_expectations(&M->xi);
+  /* F: hgaprec.cc:1407-1414 */
+  memset(M->tmpN, 0, sizeof(double) * M->m);
+  gp_sum_cols(&M->beta, M->tmpN);
+  { double v = K * M->eta.sprior;
+    for (uint32_t i = 0; i < M->m; ++i) M->eta.snext[i] += v;
+    for (uint32_t i = 0; i < M->m; ++i) M->eta.rnext[i] += M->tmpN[i]; }
+  gp_swap(&M->eta); gp_compute_expectations(&M->eta);
+}
+
+static void iterate_flat(orc_model *M)  /* vb(): hgaprec.cc:927-956 ; vb_bias(): 1226-1272 */
+{
+  const uint32_t K = M->K;
+  sweep_nonzeros(M);
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->beta, M->tmpK);
+  for (uint32_t k = 0; k < K; ++k) M->theta.rnext[k] += M->tmpK[k];  /* gpbase.hh:558-562 */
+  gp_swap(&M->theta); gp_compute_expectations(&M->theta);
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->theta, M->tmpK);
+  for (uint32_t k = 0; k < K; ++k) M->beta.rnext[k] += M->tmpK[k];
+  gp_swap(&M->beta); gp_compute_expectations(&M->beta);
+  if (M->bias) bias_sweeps(M);
+}
+
+void orc_model_iterate(orc_model *M, int n_iters)
+{
+  for (int t = 0; t < n_iters; ++t) {
+    if (M->hier) iterate_hier(M); else iterate_flat(M);
+  }
+}
+
+/* hgaprec.cc:1563-1570 */
+static double log_factorial(uint32_t n)
+{
+  double v = log(1);
+  for (uint32_t i = 2; i <= n; ++i) v += log(i);
+  return v;
+}
+
+/* rating_likelihood_hier hgaprec.cc:1538-1560 ; rating_likelihood 1503-1536 */
+static double rating_likelihood(const orc_model *M, uint32_t p, uint32_t q, uint8_t y)
+{
+  const double *et = M->theta.Ev + (size_t)p * M->K, *eb = M->beta.Ev + (size_t)q * M->K;
+  double s = .0;
+  for (uint32_t k = 0; k < M->K; ++k) s += et[k] * eb[k];
+  if (M->bias) s += M->ubias.Ev[p] + M->ibias.Ev[q];
+  if (s < 1e-30) s = 1e-30;
+  if (M->binary) return y == 0 ? -s : log(1 - exp(-s));
+  return y * log(s) - s - log_factorial(y);
+}
+
+double orc_model_heldout_sum(const orc_model *M, const uint32_t *u,
+                             const uint32_t *i, const int32_t *y, uint64_t cnt)
+{
+  double s = .0;
+  for (uint64_t a = 0; a < cnt; ++a)       /* yval_t r = i->second: uint8 wrap */
+    s += rating_likelihood(M, u[a], i[a], (uint8_t)y[a]);
+  return s;
+}
+
+static gp *state_gp(const orc_model *M, int which)
+{
+  switch (which / 4) {
+    case 0: return (gp *)&M->theta;
+    case 1: return (gp *)&M->beta;
+    case 2: return M->hier ? (gp *)&M->xi : NULL;
+    case 3: return M->hier ? (gp *)&M->eta : NULL;
+    case 4: return M->bias ? (gp *)&M->ubias : NULL;
+    case 5: return M->bias ? (gp *)&M->ibias : NULL;
+  }
+  return NULL;
+}
+
+size_t orc_model_state(const orc_model *M, int which, const double **ptr)
+{
+  gp *g = state_gp(M, which);
+  if (!g) { *ptr = NULL; return 0; }
+  size_t ns = (size_t)g->n * g->k;
+  switch (which % 4) {
+    case 0: *ptr = g->scurr; return ns;
+    case 1: *ptr = g->rcurr; return g->rsize;
+    case 2: *ptr = g->Ev; return ns;
+    default: *ptr = g->Elogv; return ns;
+  }
+}
+
+int orc_model_set_state(orc_model *M, int which, const double *src, size_t count)
+{
+  gp *g = state_gp(M, which);
+  if (!g) return -1;
+  size_t ns = (size_t)g->n * g->k;
+  double *dst; size_t want;
+  switch (which % 4) {
+    case 0: dst = g->scurr; want = ns; break;
+    case 1: dst = g->rcurr; want = g->rsize; break;
+    case 2: dst = g->Ev; want = ns; break;
+    default: dst = g->Elogv; want = ns; break;
+  }
+  if (count != want) return -1;
+  memcpy(dst, src, count * sizeof(double));
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* TSV writers: D2Array<double>::save matrix.hh:1140-1166,              */
+/*              D1Array<double>::save matrix.hh:725-744                 */
+/* id column = IDMap lookup of the row index, else the index itself     */
+/* ------------------------------------------------------------------ */
+int orc_save_matrix(const char *path, const double *a, uint32_t rows,
+                    uint32_t cols, const uint32_t *seq2id, uint32_t nids)
+{
+  FILE *tf = fopen(path, "w");
+  if (!tf) return -1;
+  for (uint32_t i = 0; i < rows; ++i) {
+    uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
+    fprintf(tf, "%d\t", i);
+    fprintf(tf, "%d\t", id);
+    for (uint32_t k = 0; k < cols; ++k) {
+      if (k == cols - 1) fprintf(tf, "%.8f\n", a[(size_t)i * cols + k]);
+      else               fprintf(tf, "%.8f\t", a[(size_t)i * cols + k]);
+    }
+  }
+  fclose(tf);
+  return 0;
+}
+
+int orc_save_vector(const char *path, const double *a, uint32_t rows,
+                    const uint32_t *seq2id, uint32_t nids)
+{
+  FILE *tf = fopen(path, "w");
+  if (!tf) return -1;
+  for (uint32_t i = 0; i < rows; ++i) {
+    uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
+    fprintf(tf, "%d\t", i);
+    fprintf(tf, "%d\t", id);
+    fprintf(tf, "%.8f\n", a[i]);
+  }
+  fclose(tf);
+  return 0;
+}
+
+/* GP*::save_state gpbase.hh:389-398,743-752,971-980 */
+static void save_state(const char *outdir, const char *name, const gp *g,
+                       int is_array, const uint32_t *seq2id, uint32_t nids)
+{
+  char p[4096];
+  snprintf(p, sizeof p, "%s/%s_shape.tsv", outdir, name);
+  if (is_array) orc_save_vector(p, g->scurr, g->n, seq2id, nids);
+  else orc_save_matrix(p, g->scurr, g->n, g->k, seq2id, nids);
+  snprintf(p, sizeof p, "%s/%s_rate.tsv", outdir, name);
+  if (is_array) orc_save_vector(p, g->rcurr, g->n, seq2id, nids);
+  else if (g->global_rate) orc_save_vector(p, g->rcurr, g->k, seq2id, nids);
+  else orc_save_matrix(p, g->rcurr, g->n, g->k, seq2id, nids);
+  snprintf(p, sizeof p, "%s/%s.tsv", outdir, name);
+  if (is_array) orc_save_vector(p, g->Ev, g->n, seq2id, nids);
+  else orc_save_matrix(p, g->Ev, g->n, g->k, seq2id, nids);
+}
+
+/* hgaprec.cc:2137-2158 */
+static void save_model(const orc_model *M, const orc_ratings *R, const char *outdir)
+{
+  const uint32_t *s2u = R->seq2user, *s2i = R->seq2item;
+  if (M->hier) {
+    save_state(outdir, "hbeta", &M->beta, 0, s2i, R->nitems);
+    save_state(outdir, "betarate", &M->eta, 1, s2i, R->nitems);
+    save_state(outdir, "htheta", &M->theta, 0, s2u, R->nusers);
+    save_state(outdir, "thetarate", &M->xi, 1, s2u, R->nusers);
+  } else {
+    save_state(outdir, "beta", &M->beta, 0, s2i, R->nitems);
+    save_state(outdir, "theta", &M->theta, 0, s2u, R->nusers);
+  }
+  if (M->bias) {
+    /* bias objects are n x 1 GPMatrix: D2Array::save with one column */
+    save_state(outdir, "betabias", &M->ibias, 0, s2i, R->nitems);
+    save_state(outdir, "thetabias", &M->ubias, 0, s2u, R->nusers);
+  }
+}
+
+/* main.cc:234-361 + HGAPRec::vb_hier / vb / vb_bias report logic +
+   compute_likelihood hgaprec.cc:1439-1501 (stop rule) */
+int orc_run(const orc_run_args *a)
+{
+  char p[4096];
+  orc_ratings *R = orc_ratings_new(a->n, a->m, a->binary, a->rating_threshold);
+  snprintf(p, sizeof p, "%s/train.tsv", a->datadir);
+  if (orc_ratings_read_train(R, p)) { orc_ratings_free(R); return -1; }
+  { char q[4096];
+    snprintf(p, sizeof p, "%s/byusers.tsv", a->outdir);
+    snprintf(q, sizeof q, "%s/byitems.tsv", a->outdir);
+    orc_ratings_write_marginals(R, p, q); }
+  snprintf(p, sizeof p, "%s/validation.tsv", a->datadir);
+  if (orc_ratings_read_heldout(R, p, 0)) { orc_ratings_free(R); return -1; }
+  snprintf(p, sizeof p, "%s/test.tsv", a->datadir);
+  if (orc_ratings_read_heldout(R, p, 1)) { orc_ratings_free(R); return -1; }
+
+  orc_model *M = orc_model_new(R->nusers, R->nitems, a->k, a->hier, a->bias, a->binary);
+  orc_model_set_csr(M, R->rowptr, R->col, R->val);
+  snprintf(p, sizeof p, "%s/validation.txt", a->outdir); FILE *vf = fopen(p, "w");
+  snprintf(p, sizeof p, "%s/test.txt", a->outdir);       FILE *tf = fopen(p, "w");
+  if (!vf || !tf) return -1;
+  time_t start = time(0);
+  orc_model_initialize(M, a->seed);
+
+  double prev_h = .0; uint32_t nh = 0; uint32_t iter = 0; int stopped = 0;
+  while (1) {
+    if (a->hier && iter > a->max_iterations) break;     /* hgaprec.cc:1337-1339 */
+    if (!a->hier && iter > 100000u) break;              /* vb()/vb_bias() have no cap */
+    orc_model_iterate(M, 1);
+    if (iter % a->rfreq == 0) {
+      for (int w = 0; w < 2 && !stopped; ++w) {
+        uint64_t k = R->nho[w];
+        double s = orc_model_heldout_sum(M, R->ho_u[w], R->ho_i[w], R->ho_y[w], k);
+        FILE *ff = w == 0 ? vf : tf;
+        fprintf(ff, "%d\t%d\t%.9f\t%d\n", iter, (int)(time(0) - start), s / k, (int)k);
+        fflush(ff);
+        if (w != 0) continue;
+        double av = s / k; int stop = 0, why = -1;
+        if (iter > 30) {
+          if (av > prev_h && prev_h != 0 && fabs((av - prev_h) / prev_h) < 0.000001) {
+            stop = 1; why = 0;
+          } else if (av < prev_h) nh++;
+          else if (av > prev_h) nh = 0;
+          if (nh > 2) { why = 1; stop = 1; }
+        }
+        prev_h = av;
+        snprintf(p, sizeof p, "%s/max.txt", a->outdir);
+        FILE *f = fopen(p, "w");
+        fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, (int)(time(0) - start), av, why);
+        fclose(f);
+        if (stop) { save_model(M, R, a->outdir); stopped = 1; }  /* do_on_stop; exit(0) */
+      }
+      if (stopped) break;
+      save_model(M, R, a->outdir);
+    }
+    iter++;
+  }
+  fclose(vf); fclose(tf);
+  orc_model_free(M); orc_ratings_free(R);
+  return (int)iter;
+}
