@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- rating-nonzeros/sec per CAVI iteration (steps A-F) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full CAVI iteration (phi passes + row sweeps; report steps
+excluded) over one synthetic ratings matrix that is resident in HBM before the
+timed region starts.  N=1 runs BASELINE config C2 (1M x 100K, 5e7 nnz, K=100,
+-hier).  N>1 is weak scaling: every rank owns a C2-sized shard of users (its
+own 5e7 nonzeros), items are shared, and the item-side shape sums plus
+sum_u E[theta_u] go through ONE RCCL all-reduce per iteration.
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
+    """time the CPU oracle (single thread, fp64 restatement of the reference)
+    on a bounded contiguous slice of the same workload's users"""
+    from oracle import orc
+    n = rowptr.shape[0] - 1
+    s = int(np.searchsorted(rowptr, min(target_nnz, rowptr[-1])))
+    s = max(1, min(s, n))
+    nz = int(rowptr[s])
+    M = orc.Model(s, cfg["m"], cfg["K"], cfg["hier"], cfg["bias"], cfg["binary"])
+    M.set_csr(rowptr[: s + 1].copy(), col[:nz].copy(), None if val is None else val[:nz].copy())
+    t0 = time.perf_counter()
+    M.initialize(0)
+    t_init = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    M.iterate(1)
+    dt = time.perf_counter() - t0
+    log(f"[cpu_baseline] slice users={s} nnz={nz} init={t_init:.1f}s iterate={dt:.2f}s")
+    return {
+        "value": nz / dt, "unit": "rating-nonzeros/s", "cores": 1, "kind": "port",
+        "sample": f"1 CAVI iteration of oracle/liborc.so (single thread) on the first {s} users "
+                  f"({nz} nonzeros) of the same matrix, all {cfg['m']} items, K={cfg['K']}",
+        "seconds": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink n, m, nnz (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(synth.CONFIGS[args.config])
+    if args.scale != 1.0:
+        for k in ("n", "m", "nnz"):
+            cfg[k] = max(64, int(cfg[k] * args.scale))
+    n_loc, m, K = cfg["n"], cfg["m"], cfg["K"]
+
+    # ---- synthetic shard (generated on the GPU, handed over as host CSR)
+    t0 = time.perf_counter()
+    rowptr, col, val = synth.generate(n_loc, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                      seed=cfg["seed"] + 1000 * rank, device=dev,
+                                      binary=cfg["binary"], item_seed=cfg["seed"])
+    nnz_loc = int(rowptr[-1])
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] generated {n_loc} x {m}, nnz={nnz_loc} in {time.perf_counter() - t0:.1f}s")
+
+    stream = torch.cuda.current_stream(dev)
+    D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
+            device=local_rank, stream=stream.cuda_stream, n_ranks=world, rank=rank,
+            n_users_total=n_loc * world)
+    xbuf = None
+    if world > 1:
+        xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
+        D.bind_exchange_buffer(xbuf.data_ptr(), xbuf.numel())
+    t0 = time.perf_counter()
+    D.upload_csr(rowptr, col, val)
+    t_upload = time.perf_counter() - t0
+
+    # ---- bench-mode initial state (counter RNG; the parity path uses MT19937)
+    t0 = time.perf_counter()
+    st = synth.initial_state(n_loc, K, cfg["seed"] + 17 + 1000 * rank, dev)
+    D.set_state("THETA_SHAPE", st["shape"]); D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, cfg["seed"] + 29, dev)
+    D.set_state("BETA_SHAPE", st["shape"]); D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    if cfg["hier"]:
+        st = synth.initial_state(n_loc, K, cfg["seed"] + 31 + 1000 * rank, dev, prior_v=K)
+        D.set_state("XI_E", st["E"])
+        st = synth.initial_state(m, K, cfg["seed"] + 37, dev, prior_v=K)
+        D.set_state("ETA_E", st["E"])
+    if cfg["bias"]:
+        st = synth.initial_state(n_loc, K, cfg["seed"] + 41 + 1000 * rank, dev, prior_v=m)
+        D.set_state("UBIAS_E", st["E"]); D.set_state("UBIAS_ELOG", st["Elog"]); D.set_state("UBIAS_SHAPE", st["shape"])
+        st = synth.initial_state(m, K, cfg["seed"] + 43, dev, prior_v=n_loc * world)
+        D.set_state("IBIAS_E", st["E"]); D.set_state("IBIAS_ELOG", st["Elog"]); D.set_state("IBIAS_SHAPE", st["shape"])
+    del st
+    torch.cuda.empty_cache()
+    log(f"[rank {rank}] upload {t_upload:.1f}s, state {time.perf_counter() - t0:.1f}s")
+
+    def step():
+        if world == 1:
+            D.iterate(1)
+        else:
+            D.iterate_local()
+            dist.all_reduce(xbuf)          # RCCL sum over xGMI, ordered on this stream
+            D.iterate_global()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nn = torch.tensor([nnz_loc], dtype=torch.float64, device=dev)
+        dist.all_reduce(nn)
+        nnz_total = int(nn.item())
+    else:
+        nnz_total = nnz_loc
+
+    tm = D.mean_timing(min(args.steps, 64))
+    ab = D.algorithmic_bytes()
+    if rank == 0:
+        # dominant kernel of the iteration and its HBM roofline position
+        kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
+        kms = tm[kern + "_ms"]
+        achieved = ab[kern] / (kms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(f"{args.config}:{kern}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rating-nonzeros/sec per CAVI iter (K=%d)" % K,
+            "value": nnz_total * args.steps / dt,
+            "unit": "rating-nonzeros/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: synthetic power-law ratings, {n_loc} users x {m} items "
+                            f"and {nnz_loc} nonzeros per GPU, K={K}, "
+                            + " ".join(f for f, on in (("-hier", cfg["hier"]), ("-bias", cfg["bias"]),
+                                                       ("-binary-data", cfg["binary"])) if on),
+                "users_per_gpu": n_loc, "items": m, "nnz_per_gpu": nnz_loc, "nnz_total": nnz_total,
+                "K": K, "sharding": "users (contiguous ranges); items replicated; 1 all-reduce/iter"
+                if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": f"phi_pass_kernel ({kern} pass)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": ab[kern], "avg_launch_ms": kms,
+            },
+            "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+            "iteration_algorithmic_GBps": (ab["phi_user"] + ab["phi_item"] + ab["rows"]) / (dt / args.steps) / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, rowptr, col, val)
+        print(json.dumps(out), flush=True)
+    D.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,7 @@ EXPORTS = [
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
     "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
+    "hpf_mean_timing",
     "hpf_algorithmic_bytes",
 ]
 
@@ -94,6 +95,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
                                    C.POINTER(C.c_uint64)]
     lib.hpf_synchronize.argtypes = [vp]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
+    lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
     lib.hpf_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]
     if path is None:
@@ -226,6 +228,11 @@ class Hpf:
     def last_timing(self) -> dict:
         t = HpfTiming()
         self._check(self.lib.hpf_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
+
+    def mean_timing(self, n_last: int) -> dict:
+        t = HpfTiming()
+        self._check(self.lib.hpf_mean_timing(self._h, int(n_last), C.byref(t)))
         return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
 
     def algorithmic_bytes(self) -> dict:

@@ -61,8 +61,10 @@ struct hpf_handle {
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
   uint32_t seg_max = 512;
   uint32_t phi_blocks = 2048;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  static constexpr uint32_t RING = 64;          // timed iterations kept
+  hipEvent_t evr[RING][5] = {};
+  hipEvent_t *ev = evr[0];                      // events of the iteration in flight
+  uint32_t ev_count = 0;                        // iterations recorded so far
   std::string err;
 };
 
@@ -376,6 +378,7 @@ int iterate_local(hpf_handle *h)
   int rc;
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
   if ((rc = prepare_derived(h))) return rc;
+  h->ev = h->evr[h->ev_count % hpf_handle::RING];
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   if ((rc = run_phi(h, h->u, h->it))) return rc;           // step A, theta shape sums
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -393,7 +396,7 @@ int iterate_global(hpf_handle *h)
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
   if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
   HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-  h->ev_valid = true;
+  h->ev_count++;
   h->iterations++;
   return HPF_OK;
 }
@@ -449,8 +452,9 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_ERR_HIP);
     h->own_stream = true;
   }
-  for (int e = 0; e < 5; ++e)
-    if (hipEventCreate(&h->ev[e]) != hipSuccess) return fail(HPF_ERR_HIP);
+  for (uint32_t r = 0; r < hpf_handle::RING; ++r)
+    for (int e = 0; e < 5; ++e)
+      if (hipEventCreate(&h->evr[r][e]) != hipSuccess) return fail(HPF_ERR_HIP);
 
   // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
   h->phiV = 1;
@@ -522,7 +526,8 @@ void hpf_destroy(hpf_handle *h)
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
   dfree(h->logfact);
-  for (int e = 0; e < 5; ++e) if (h->ev[e]) (void)hipEventDestroy(h->ev[e]);
+  for (uint32_t r = 0; r < hpf_handle::RING; ++r)
+    for (int e = 0; e < 5; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -777,20 +782,34 @@ int hpf_synchronize(hpf_handle *h)
   return HPF_OK;
 }
 
-int hpf_last_timing(hpf_handle *h, hpf_timing *out)
+int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
 {
   if (!h || !out) return HPF_ERR_INVALID;
   memset(out, 0, sizeof *out);
   out->iterations = h->iterations;
-  if (!h->ev_valid) return HPF_OK;
-  HIPCHK(h, hipEventSynchronize(h->ev[4]));
-  HIPCHK(h, hipEventElapsedTime(&out->phi_user_ms, h->ev[0], h->ev[1]));
-  HIPCHK(h, hipEventElapsedTime(&out->phi_item_ms, h->ev[1], h->ev[2]));
-  HIPCHK(h, hipEventElapsedTime(&out->sweep_user_ms, h->ev[2], h->ev[3]));
-  HIPCHK(h, hipEventElapsedTime(&out->sweep_item_ms, h->ev[3], h->ev[4]));
-  HIPCHK(h, hipEventElapsedTime(&out->iteration_ms, h->ev[0], h->ev[4]));
+  uint32_t n = std::min<uint32_t>(std::min<uint32_t>(n_last, h->ev_count), hpf_handle::RING);
+  if (n == 0) return HPF_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (uint32_t k = 0; k < n; ++k) {
+    hipEvent_t *ev = h->evr[(h->ev_count - 1 - k) % hpf_handle::RING];
+    float ms[5];
+    HIPCHK(h, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&ms[2], ev[2], ev[3]));
+    HIPCHK(h, hipEventElapsedTime(&ms[3], ev[3], ev[4]));
+    HIPCHK(h, hipEventElapsedTime(&ms[4], ev[0], ev[4]));
+    for (int j = 0; j < 5; ++j) acc[j] += ms[j];
+  }
+  out->phi_user_ms = (float)(acc[0] / n);
+  out->phi_item_ms = (float)(acc[1] / n);
+  out->sweep_user_ms = (float)(acc[2] / n);
+  out->sweep_item_ms = (float)(acc[3] / n);
+  out->iteration_ms = (float)(acc[4] / n);
   return HPF_OK;
 }
+
+int hpf_last_timing(hpf_handle *h, hpf_timing *out) { return hpf_mean_timing(h, 1, out); }
 
 int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item, uint64_t *rows)
 {

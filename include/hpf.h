@@ -88,8 +88,9 @@ typedef struct {
   double   r_prior;        /* 0.3                                            */
 } hpf_config;
 
-/* per-kernel device time of the most recent iteration, milliseconds, from
- * hipEvents recorded on the handle's stream */
+/* per-kernel device time, milliseconds, from hipEvents recorded on the
+ * handle's stream around each launch group (in multi-rank use sweep_item_ms
+ * also spans the caller's all-reduce between iterate_local and _global) */
 typedef struct {
   float phi_user_ms;    /* K1a: user-major phi pass (theta shape sums)       */
   float phi_item_ms;    /* K1b: item-major phi pass (beta shape sums)        */
@@ -156,6 +157,8 @@ int  hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i,
 
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
+/* mean over the last n_last iterations (at most 64 are kept); synchronises */
+int  hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out);
 
 /* algorithmic bytes (SURVEY.md section 8d / DESIGN.md) moved by one launch of
  * the two phi passes and of the row sweeps for the uploaded matrix */
