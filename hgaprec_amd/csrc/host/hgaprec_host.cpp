@@ -1,0 +1,538 @@
+// hgaprec_host.cpp -- see hgaprec_host.hpp.  Plain C++17, no HIP.
+#include "hgaprec_host.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <numeric>
+#include <sstream>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+namespace hgaprec {
+
+// ======================================================================
+// Env
+// ======================================================================
+int Env::parse(int argc, char **argv, bool echo, std::string *bad)
+{
+  // same flag set and defaults as main.cc:41-232.  Flags that select modes
+  // outside the CAVI hot path are accepted (they are valid options of the
+  // CLI) and remembered in `unsupported`.
+  auto out_of_scope = [&](const char *f) { if (unsupported.empty()) unsupported = f; };
+  for (int i = 0; i < argc; ++i) {
+    const char *s = argv[i];
+    auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
+    if (!strcmp(s, "-dir")) { datfname = next(); if (echo) fprintf(stdout, "+ dir = %s\n", datfname.c_str()); }
+    else if (!strcmp(s, "-n")) { n = (uint32_t)atoi(next()); if (echo) fprintf(stdout, "+ n = %d\n", n); }
+    else if (!strcmp(s, "-p")) { }
+    else if (!strcmp(s, "-m")) { m = (uint32_t)atoi(next()); if (echo) fprintf(stdout, "+ m = %d\n", m); }
+    else if (!strcmp(s, "-k")) { k = (uint32_t)atoi(next()); if (echo) fprintf(stdout, "+ k = %d\n", k); }
+    else if (!strcmp(s, "-nmi")) { next(); out_of_scope("-nmi"); }
+    else if (!strcmp(s, "-rfreq")) { rfreq = (uint32_t)atoi(next()); if (echo) fprintf(stdout, "+ rfreq = %d\n", rfreq); }
+    else if (!strcmp(s, "-strid")) { out_of_scope("-strid"); }
+    else if (!strcmp(s, "-label")) { label = next(); }
+    else if (!strcmp(s, "-logl")) { logl = true; if (echo) fprintf(stdout, "+ logl mode\n"); }
+    else if (!strcmp(s, "-max-iterations")) { max_iterations = (uint32_t)atoi(next()); if (echo) fprintf(stdout, "+ max iterations %d\n", max_iterations); }
+    else if (!strcmp(s, "-seed")) { seed = atof(next()); if (echo) fprintf(stdout, "+ random seed set to %.5f\n", seed); }
+    else if (!strcmp(s, "-load")) { next(); }   // parsed, never consulted (main.cc:137-140)
+    else if (!strcmp(s, "-test")) { out_of_scope("-test"); }
+    else if (!strcmp(s, "-batch")) { batch = true; if (echo) fprintf(stdout, "+ batch inference\n"); }
+    else if (!strcmp(s, "-online")) { batch = false; if (echo) fprintf(stdout, "+ online inference\n"); }
+    else if (!strcmp(s, "-gen-heldout")) { out_of_scope("-gen-heldout"); }
+    else if (!strcmp(s, "-pred-accuracy") || !strcmp(s, "-gt-accuracy")) { }
+    else if (!strcmp(s, "-netflix") || !strcmp(s, "-mendeley") || !strcmp(s, "-movielens") ||
+             !strcmp(s, "-echonest")) { }   // dataset tag: only used by CREATE_TRAIN_TEST_SETS (dead)
+    else if (!strcmp(s, "-nyt")) { out_of_scope("-nyt"); }
+    else if (!strcmp(s, "-a")) { a = atof(next()); }
+    else if (!strcmp(s, "-b")) { b = atof(next()); }
+    else if (!strcmp(s, "-c")) { c = atof(next()); }
+    else if (!strcmp(s, "-d")) { d = atof(next()); }
+    else if (!strcmp(s, "-binary-data")) { binary_data = true; }
+    else if (!strcmp(s, "-bias")) { bias = true; }
+    else if (!strcmp(s, "-hier")) { hier = true; }
+    else if (!strcmp(s, "-mle-user") || !strcmp(s, "-mle-item") || !strcmp(s, "-canny") ||
+             !strcmp(s, "-gen-ranking") || !strcmp(s, "-rmse") || !strcmp(s, "-msr") ||
+             !strcmp(s, "-nmf") || !strcmp(s, "-nmfload") || !strcmp(s, "-vwload") ||
+             !strcmp(s, "-lda") || !strcmp(s, "-vwlda") || !strcmp(s, "-write-training") ||
+             !strcmp(s, "-chi") || !strcmp(s, "-chinmf") || !strcmp(s, "-als") ||
+             !strcmp(s, "-wals") || !strcmp(s, "-climf") || !strcmp(s, "-ctr")) { out_of_scope(s); }
+    else if (!strcmp(s, "-novb")) { vb = false; }
+    else if (!strcmp(s, "-wals_l") || !strcmp(s, "-wals_C")) { next(); }
+    else if (!strcmp(s, "-rating-threshold")) { rating_threshold = (uint32_t)atoi(next()); }
+    else if (!strcmp(s, "-device")) { device = atoi(next()); }      // extension: HIP device ordinal
+    else if (i > 0) {
+      if (bad) *bad = s;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+std::string Env::make_prefix() const
+{
+  std::ostringstream sa;
+  sa << "n" << n << "-";
+  sa << "m" << m << "-";
+  sa << "k" << k;
+  if (label != "") sa << "-" << label;
+  else if (datfname.length() > 3) {
+    std::string q = datfname.substr(0, 2);
+    if (isalpha((unsigned char)q[0])) sa << "-" << q;
+  }
+  if (a != 0.3) sa << "-a" << a;
+  if (b != 0.3) sa << "-b" << b;
+  if (c != 0.3) sa << "-c" << c;
+  if (d != 0.3) sa << "-d" << d;
+  if (batch) sa << "-batch"; else sa << "-online";
+  if (binary_data) sa << "-bin";
+  if (bias) sa << "-bias";
+  if (hier) sa << "-hier";
+  if (vb) sa << "-vb";
+  if (seed) sa << "-seed" << seed;
+  return sa.str();
+}
+
+int Env::open_output()
+{
+  prefix = make_prefix();
+  fprintf(stdout, "+ Creating directory %s\n", prefix.c_str());
+  fflush(stdout);
+  struct stat st;
+  if (stat(prefix.c_str(), &st) != 0) {            // log.cc:97-118, force = true
+    if (errno != ENOENT) { fprintf(stderr, "Warning: could not stat dir %s\n", prefix.c_str()); return -1; }
+    mkdir(prefix.c_str(), S_IRWXU | S_IRWXG | S_IROTH | S_IXOTH);
+    if (stat(prefix.c_str(), &st) != 0) { fprintf(stderr, "Warning: could not create dir %s\n", prefix.c_str()); return -1; }
+  }
+  std::string lf = prefix + "/infer.log";
+  logf = fopen(lf.c_str(), "w");
+  if (logf) fprintf(stderr, "+ writing log to %s\n", lf.c_str());
+  else { logf = fopen("/dev/null", "w"); fprintf(stderr, "+ writing log to /dev/null\n"); }
+  plogf = fopen(file_str("/param.txt").c_str(), "w");
+  if (!plogf) { printf("cannot open param file:%s\n", strerror(errno)); return -1; }
+  // env.hh:383-402.  (-a..-d only reach the directory name and these lines;
+  // every Gamma object is built with the literal 0.3 prior, hgaprec.cc:13-20)
+  plog("n", n); plog("k", k); plog("t", (uint32_t)2);
+  plog("test_ratio", 0.2); plog("validation_ratio", 0.01);
+  plog("seed", seed); plog("a", a); plog("b", b); plog("c", c); plog("d", d);
+  plog("reportfreq", rfreq); plog("vb", vb); plog("bias", bias); plog("hier", hier);
+  plog("nmf", false); plog("lda", false); plog("wals_l", 0.1); plog("wals_C", (uint32_t)10);
+  plog("mle_user", false); plog("mle_item", false);
+  return 0;
+}
+
+void Env::close_output()
+{
+  if (plogf) fclose(plogf);
+  if (logf) fclose(logf);
+  plogf = logf = nullptr;
+}
+
+void Env::plog(const std::string &key, double v) { fprintf(plogf, "%s: %.9f\n", key.c_str(), v); fflush(plogf); }
+void Env::plog(const std::string &key, bool v) { fprintf(plogf, "%s: %s\n", key.c_str(), v ? "True" : "False"); fflush(plogf); }
+void Env::plog(const std::string &key, uint32_t v) { fprintf(plogf, "%s: %d\n", key.c_str(), v); fflush(plogf); }
+void Env::plog(const std::string &key, uint64_t v) { fprintf(plogf, "%s: %lu\n", key.c_str(), (unsigned long)v); fflush(plogf); }
+void Env::plog(const std::string &key, const std::string &v) { fprintf(plogf, "%s: %s\n", key.c_str(), v.c_str()); fflush(plogf); }
+
+void Env::lerr(const char *fmt, ...)
+{
+  if (!logf) return;
+  time_t now = time(0); struct tm p; localtime_r(&now, &p);
+  char ts[64]; strftime(ts, sizeof ts, "%b %e %T", &p);
+  fprintf(logf, "[%s] [%d] [%3s] ", ts, (int)getpid(), "ERR");     // log.cc:26-46
+  va_list ap; va_start(ap, fmt); vfprintf(logf, fmt, ap); va_end(ap);
+  fprintf(logf, "\n\n");
+  fflush(logf);
+}
+
+// ======================================================================
+// Ratings
+// ======================================================================
+static inline uint32_t hash32(uint32_t k) { k *= 2654435761u; return k ^ (k >> 15); }
+
+void Ratings::IdMap::rehash(uint32_t cap)
+{
+  std::vector<uint32_t> ok(std::move(keys)), ov(std::move(vals)); std::vector<uint8_t> ou(std::move(used));
+  keys.assign(cap, 0); vals.assign(cap, 0); used.assign(cap, 0); cnt = 0;
+  for (size_t i = 0; i < ou.size(); ++i) if (ou[i]) put(ok[i], ov[i]);
+}
+bool Ratings::IdMap::find(uint32_t key, uint32_t *val) const
+{
+  const uint32_t mask = (uint32_t)keys.size() - 1;
+  for (uint32_t i = hash32(key) & mask; used[i]; i = (i + 1) & mask)
+    if (keys[i] == key) { *val = vals[i]; return true; }
+  return false;
+}
+void Ratings::IdMap::put(uint32_t key, uint32_t val)
+{
+  if ((uint64_t)(cnt + 1) * 2 > keys.size()) rehash((uint32_t)keys.size() * 2);
+  const uint32_t mask = (uint32_t)keys.size() - 1;
+  uint32_t i = hash32(key) & mask;
+  for (; used[i]; i = (i + 1) & mask) if (keys[i] == key) { vals[i] = val; return; }
+  used[i] = 1; keys[i] = key; vals[i] = val; cnt++;
+}
+
+uint32_t Ratings::input_rating_class(uint32_t v) const     // ratings.hh:191-197
+{
+  if (!binary) return v;
+  return v >= rating_threshold ? 1 : 0;
+}
+
+// buffered whitespace-separated unsigned reader with fscanf("%u\t%u\t%u\n")
+// semantics for well-formed files (any whitespace separates fields)
+namespace {
+struct Tok {
+  FILE *f; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+  explicit Tok(FILE *ff) : f(ff), buf(1 << 20) {}
+  int peek() {
+    if (pos == len) {
+      if (eof) return -1;
+      len = fread(buf.data(), 1, buf.size(), f); pos = 0;
+      if (len == 0) { eof = true; return -1; }
+    }
+    return (unsigned char)buf[pos];
+  }
+  void skip_ws() { int c; while ((c = peek()) >= 0 && isspace(c)) ++pos; }
+  // 1 = number read, 0 = matching failure (non-numeric), -1 = EOF before any digit
+  int next_u32(uint32_t *out) {
+    skip_ws();
+    int c = peek();
+    if (c < 0) return -1;
+    bool neg = false;
+    if (c == '+' || c == '-') { neg = (c == '-'); ++pos; c = peek(); }
+    if (c < 0 || !isdigit(c)) return 0;
+    uint64_t v = 0;
+    while ((c = peek()) >= 0 && isdigit(c)) { v = v * 10 + (uint64_t)(c - '0'); if (v > 0xffffffffffffull) v &= 0xffffffffull; ++pos; }
+    uint32_t r = (uint32_t)v;
+    *out = neg ? (uint32_t)(0u - r) : r;
+    return 1;
+  }
+  bool at_eof() { skip_ws(); return peek() < 0; }
+};
+}  // namespace
+
+int Ratings::read_generic(FILE *f, HeldOut *out)
+{
+  Tok tk(f);
+  uint32_t mid = 0, uid = 0, rating = 0;        // persist across lines like the reference's locals
+  // capacity for this pass: ratings.cc:35-36 shrinks env.n / env.m to the
+  // registered counts once the training file has been read
+  const uint32_t lim_n = out ? n : cap_n, lim_m = out ? m : cap_m;
+  std::vector<uint64_t> ord;                    // held-out insertion order
+  bool first = true;
+  while (true) {
+    // while (!feof(f)) { if (fscanf(...) < 0) exit(-1); ... }
+    if (!first && tk.at_eof()) break;           // the trailing "\n" directive ate the whitespace
+    first = false;
+    int r1 = tk.next_u32(&uid);
+    if (r1 < 0) { printf("error: unexpected lines in file\n"); return -2; }   // empty file: ratings.cc:71-75
+    // EOF inside the last record: fscanf returns 1 or 2 (>= 0) and the
+    // reference goes on with the stale values of the missing fields
+    int r2 = r1 == 1 ? tk.next_u32(&mid) : 0;
+    int r3 = r2 == 1 ? tk.next_u32(&rating) : (r2 < 0 ? -1 : 0);
+    if (r1 == 0 || r2 == 0 || r3 == 0) {
+      // a non-numeric token: the reference never consumes it and loops forever
+      fprintf(stderr, "error: malformed line in ratings file\n");
+      return -2;
+    }
+    uint32_t us = 0, ms = 0;
+    const bool hasu = user2seq.find(uid, &us), hasm = item2seq.find(mid, &ms);
+    if ((!hasu && n >= lim_n) || (!hasm && m >= lim_m)) continue;
+    if (input_rating_class(rating) == 0) continue;
+    if (!hasu) { us = n; user2seq.put(uid, us); seq2user.push_back(uid); n++; }     // ratings.hh:117-133
+    if (!hasm) { ms = m; item2seq.put(mid, ms); seq2item.push_back(mid); m++; }     // ratings.hh:135-151
+    if (!out) {
+      nratings++;
+      tr_u_.push_back(us); tr_i_.push_back(ms); tr_y_.push_back(rating);
+    } else {
+      out->u.push_back(us); out->i.push_back(ms);
+      out->y.push_back(binary ? 1 : (int32_t)rating);
+    }
+  }
+  return 0;
+}
+
+int Ratings::read_train(const std::string &path)
+{
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) { fprintf(stderr, "error: cannot open file %s:%s", path.c_str(), strerror(errno)); return -1; }
+  n = m = 0; nratings = 0;
+  int rc = read_generic(f, nullptr);
+  fclose(f);
+  if (rc) return rc;
+  // CSR: rows by user seq, inside a row the file order (ratings.cc:105
+  // push_back); the rating used for every copy of a duplicated (u,i) is the
+  // LAST one written to the per-user std::map<item,uint8_t> (ratings.cc:96-103)
+  const uint64_t nnz = tr_u_.size();
+  rowptr.assign((size_t)n + 1, 0);
+  for (uint64_t j = 0; j < nnz; ++j) rowptr[(size_t)tr_u_[j] + 1]++;
+  for (uint32_t u = 0; u < n; ++u) rowptr[u + 1] += rowptr[u];
+  col.resize(nnz); val.resize(nnz);
+  {
+    std::vector<int64_t> next(rowptr.begin(), rowptr.end() - 1);
+    for (uint64_t j = 0; j < nnz; ++j) {
+      const int64_t p = next[tr_u_[j]]++;
+      col[(size_t)p] = tr_i_[j];
+      val[(size_t)p] = binary ? 1 : (uint8_t)tr_y_[j];       // yval_t = uint8_t (env.hh:20)
+    }
+  }
+  std::vector<uint32_t> perm;
+  for (uint32_t u = 0; u < n; ++u) {
+    const int64_t a = rowptr[u], b = rowptr[u + 1];
+    if (b - a < 2) continue;
+    perm.resize((size_t)(b - a));
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return col[a + x] < col[a + y]; });
+    for (size_t s = 0; s < perm.size();) {
+      size_t e = s;
+      while (e + 1 < perm.size() && col[a + perm[e + 1]] == col[a + perm[s]]) ++e;
+      if (e > s) { const uint8_t last = val[a + perm[e]]; for (size_t t = s; t <= e; ++t) val[a + perm[t]] = last; }
+      s = e + 1;
+    }
+  }
+  std::vector<uint32_t>().swap(tr_u_); std::vector<uint32_t>().swap(tr_i_); std::vector<uint32_t>().swap(tr_y_);
+  return 0;
+}
+
+int Ratings::read_heldout(const std::string &path, HeldOut *out)
+{
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  HeldOut raw;
+  int rc = read_generic(f, &raw);
+  fclose(f);
+  if (rc) return rc;
+  // std::map<Rating,int>: sorted by (user, item), last assignment wins
+  const size_t cnt = raw.u.size();
+  std::vector<uint32_t> p(cnt);
+  std::iota(p.begin(), p.end(), 0u);
+  std::stable_sort(p.begin(), p.end(), [&](uint32_t x, uint32_t y) {
+    return raw.u[x] != raw.u[y] ? raw.u[x] < raw.u[y] : raw.i[x] < raw.i[y]; });
+  out->u.clear(); out->i.clear(); out->y.clear();
+  for (size_t s = 0; s < cnt;) {
+    size_t e = s;
+    while (e + 1 < cnt && raw.u[p[e + 1]] == raw.u[p[s]] && raw.i[p[e + 1]] == raw.i[p[s]]) ++e;
+    out->u.push_back(raw.u[p[e]]); out->i.push_back(raw.i[p[e]]); out->y.push_back(raw.y[p[e]]);
+    s = e + 1;
+  }
+  return 0;
+}
+
+int Ratings::write_marginals(const std::string &byusers, const std::string &byitems,
+                             uint32_t *lu, uint32_t *li) const
+{
+  FILE *f = fopen(byusers.c_str(), "w");
+  if (!f) return -1;
+  uint32_t x = 0;
+  for (uint32_t u = 0; u < n; ++u) {
+    const int64_t a = rowptr[u], b = rowptr[u + 1];
+    if (a == b) { x++; continue; }
+    uint32_t t = 0;
+    for (int64_t j = a; j < b; ++j) t += val[(size_t)j];
+    x = 0;
+    fprintf(f, "%d\t%d\t%d\t%d\n", u, seq2user[u], (int)(b - a), t);
+  }
+  fclose(f);
+  if (lu) *lu = x;
+  std::vector<uint32_t> deg(m, 0), sum(m, 0);
+  for (size_t j = 0; j < col.size(); ++j) { deg[col[j]]++; sum[col[j]] += val[j]; }
+  f = fopen(byitems.c_str(), "w");
+  if (!f) return -1;
+  x = 0;
+  for (uint32_t i = 0; i < m; ++i) {
+    if (!deg[i]) { x++; continue; }
+    x = 0;
+    fprintf(f, "%d\t%d\t%d\t%d\n", i, seq2item[i], deg[i], sum[i]);
+  }
+  fclose(f);
+  if (li) *li = x;
+  return 0;
+}
+
+// ======================================================================
+// MT19937 (Matsumoto & Nishimura; GSL's gsl_rng_mt19937 conventions)
+// ======================================================================
+void Mt19937::set(unsigned long s)
+{
+  if (s == 0) s = 4357;                          // GSL default seed
+  mt[0] = (uint32_t)(s & 0xffffffffUL);
+  for (int i = 1; i < 624; ++i)
+    mt[i] = (uint32_t)(1812433253UL * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned long)i);
+  mti = 624;
+}
+
+uint32_t Mt19937::next_u32()
+{
+  if (mti >= 624) {
+    auto twist = [](uint32_t u, uint32_t v) {
+      const uint32_t y = (u & 0x80000000U) | (v & 0x7fffffffU);
+      return (y >> 1) ^ ((v & 1U) ? 0x9908b0dfU : 0U);
+    };
+    int kk = 0;
+    for (; kk < 624 - 397; ++kk) mt[kk] = mt[kk + 397] ^ twist(mt[kk], mt[kk + 1]);
+    for (; kk < 623; ++kk) mt[kk] = mt[kk + (397 - 624)] ^ twist(mt[kk], mt[kk + 1]);
+    mt[623] = mt[396] ^ twist(mt[623], mt[0]);
+    mti = 0;
+  }
+  uint32_t k = mt[mti++];
+  k ^= (k >> 11);
+  k ^= (k << 7) & 0x9d2c5680U;
+  k ^= (k << 15) & 0xefc60000U;
+  k ^= (k >> 18);
+  return k;
+}
+
+unsigned long Mt19937::uniform_int(unsigned long n)
+{
+  const unsigned long scale = 0xffffffffUL / n;
+  unsigned long k;
+  do { k = next_u32() / scale; } while (k >= n);
+  return k;
+}
+
+Mt19937 make_rng(double env_seed)
+{
+  // gsl_rng_env_setup(): GSL_RNG_SEED sets gsl_rng_default_seed; gsl_rng_alloc
+  // seeds with it; then "if (_env.seed) gsl_rng_set(_r, _env.seed)"
+  unsigned long def = 0;
+  if (const char *e = getenv("GSL_RNG_SEED")) def = strtoul(e, nullptr, 0);
+  Mt19937 r(def);
+  if (env_seed) r.set((unsigned long)env_seed);
+  return r;
+}
+
+// digamma, x > 0: recurrence to x >= 10, asymptotic series through x^-14
+double digamma(double x)
+{
+  double acc = 0.0;
+  while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
+  const double xi = 1.0 / x, x2 = xi * xi;
+  const double s = x2 * (1.0 / 12 - x2 * (1.0 / 120 - x2 * (1.0 / 252 - x2 * (1.0 / 240 -
+                   x2 * (1.0 / 132 - x2 * (691.0 / 32760 - x2 * (1.0 / 12)))))));
+  return acc + std::log(x) - 0.5 * xi - s;
+}
+
+// ======================================================================
+// HGAPRec::initialize (hgaprec.cc:153-204)
+// ======================================================================
+namespace {
+const double SPRIOR = 0.3, RPRIOR = 0.3;       // hgaprec.cc:13-20
+
+// GPMatrix::initialize (gpbase.hh:292-308): n*k shape draws, then k rate draws
+void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate,
+                   std::vector<double> &shape, std::vector<double> &rate)
+{
+  shape.resize((size_t)rows * k);
+  for (size_t e = 0; e < shape.size(); ++e) shape[e] = SPRIOR + 0.01 * r.uniform();
+  std::vector<double> b0(k);
+  for (uint32_t j = 0; j < k; ++j) b0[j] = RPRIOR + 0.1 * r.uniform();
+  if (global_rate) rate = b0;                   // GPMatrixGR::initialize gpbase.hh:651-663
+  else {
+    rate.resize((size_t)rows * k);
+    for (uint32_t i = 0; i < rows; ++i) for (uint32_t j = 0; j < k; ++j) rate[(size_t)i * k + j] = b0[j];
+  }
+}
+// initialize_exp (gpbase.hh:324-340 / 700-715): fresh rate draw per element
+void gp_initialize_exp(Mt19937 &r, const std::vector<double> &shape,
+                       std::vector<double> &E, std::vector<double> &Elog)
+{
+  E.resize(shape.size()); Elog.resize(shape.size());
+  for (size_t e = 0; e < shape.size(); ++e) {
+    const double b = RPRIOR + 0.1 * r.uniform();
+    E[e] = shape[e] / b;
+    Elog[e] = digamma(shape[e]) - std::log(b);
+  }
+}
+// initialize2(v) + compute_expectations (gpbase.hh:310-322,939-949; 248-262,912-925)
+void gp_initialize2(Mt19937 &r, uint32_t rows, double v, std::vector<double> &shape,
+                    std::vector<double> &rate, std::vector<double> &E, std::vector<double> &Elog)
+{
+  shape.resize(rows); rate.resize(rows); E.resize(rows); Elog.resize(rows);
+  for (uint32_t i = 0; i < rows; ++i) { shape[i] = SPRIOR + 0.01 * r.uniform(); rate[i] = RPRIOR + v; }
+  for (uint32_t i = 0; i < rows; ++i) { E[i] = shape[i] / rate[i]; Elog[i] = digamma(shape[i]) - std::log(rate[i]); }
+}
+}  // namespace
+
+void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hier,
+                      bool bias, GammaState *s)
+{
+  s->n = n; s->m = m; s->k = k; s->hier = hier; s->bias = bias;
+  if (!hier) {                                   // hgaprec.cc:156-161
+    gp_initialize(rng, m, k, true, s->beta_shape, s->beta_rate);
+    gp_initialize(rng, n, k, true, s->theta_shape, s->theta_rate);
+    gp_initialize_exp(rng, s->beta_shape, s->beta_E, s->beta_Elog);
+    gp_initialize_exp(rng, s->theta_shape, s->theta_E, s->theta_Elog);
+  } else {                                       // hgaprec.cc:173-193
+    gp_initialize2(rng, n, (double)k, s->xi_shape, s->xi_rate, s->xi_E, s->xi_Elog);
+    gp_initialize2(rng, m, (double)k, s->eta_shape, s->eta_rate, s->eta_E, s->eta_Elog);
+    gp_initialize(rng, m, k, false, s->beta_shape, s->beta_rate);
+    gp_initialize_exp(rng, s->beta_shape, s->beta_E, s->beta_Elog);
+    gp_initialize(rng, n, k, false, s->theta_shape, s->theta_rate);
+    gp_initialize_exp(rng, s->theta_shape, s->theta_E, s->theta_Elog);
+  }
+  if (bias) {                                    // hgaprec.cc:197-203
+    gp_initialize2(rng, n, (double)m, s->ubias_shape, s->ubias_rate, s->ubias_E, s->ubias_Elog);
+    gp_initialize2(rng, m, (double)n, s->ibias_shape, s->ibias_rate, s->ibias_E, s->ibias_Elog);
+  }
+}
+
+// ======================================================================
+// writers
+// ======================================================================
+int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
+                const uint32_t *seq2id, uint32_t nids)
+{
+  FILE *tf = fopen(path.c_str(), "w");
+  if (!tf) return -1;
+  std::vector<char> big(1 << 20);
+  setvbuf(tf, big.data(), _IOFBF, big.size());
+  for (uint32_t i = 0; i < rows; ++i) {
+    const uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
+    fprintf(tf, "%d\t", i);
+    fprintf(tf, "%d\t", id);
+    for (uint32_t k = 0; k < cols; ++k)
+      fprintf(tf, (k == cols - 1) ? "%.8f\n" : "%.8f\t", a[(size_t)i * cols + k]);
+  }
+  fclose(tf);
+  return 0;
+}
+
+int save_vector(const std::string &path, const double *a, uint32_t rows,
+                const uint32_t *seq2id, uint32_t nids)
+{
+  FILE *tf = fopen(path.c_str(), "w");
+  if (!tf) return -1;
+  for (uint32_t i = 0; i < rows; ++i) {
+    const uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
+    fprintf(tf, "%d\t", i);
+    fprintf(tf, "%d\t", id);
+    fprintf(tf, "%.8f\n", a[i]);
+  }
+  fclose(tf);
+  return 0;
+}
+
+// ======================================================================
+// stop rule (hgaprec.cc:1476-1492)
+// ======================================================================
+bool StopRule::update(uint32_t iter, double a, int *why)
+{
+  bool stop = false;
+  *why = -1;
+  if (iter > 30) {
+    if (a > prev_h && prev_h != 0 && std::fabs((a - prev_h) / prev_h) < 0.000001) { stop = true; *why = 0; }
+    else if (a < prev_h) nh++;
+    else if (a > prev_h) nh = 0;
+    if (nh > 2) { *why = 1; stop = true; }
+  }
+  prev_h = a;
+  return stop;
+}
+
+}  // namespace hgaprec

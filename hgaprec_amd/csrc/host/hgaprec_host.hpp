@@ -1,0 +1,144 @@
+// hgaprec_host.hpp -- host side of the reference interface (no HIP here).
+//
+// Mirrors, for the hot path only, what the reference keeps on the host:
+//   Env        CLI flags, output-directory name, param.txt   (src/main.cc:99-243, src/env.hh:216-408)
+//   Ratings    train/validation/test.tsv -> CSR + held-out lists (src/ratings.cc:63-119,217-271)
+//   Mt19937    the gsl_rng_default stream                    (hgaprec.cc:34-38)
+//   GammaInit  HGAPRec::initialize draw order                (hgaprec.cc:153-204, gpbase.hh:292-340,939-949)
+//   save_*     factor TSV writers                            (matrix.hh:725-744,1140-1166)
+// The device side is reached only through include/hpf.h.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace hgaprec {
+
+// ---------------------------------------------------------------- Env -----
+struct Env {
+  // values as main.cc:41-97 initialises them
+  std::string datfname, label;
+  uint32_t n = 0, m = 0, k = 0;
+  uint32_t rfreq = 10, max_iterations = 1000, rating_threshold = 1;
+  double seed = 0, a = 0.3, b = 0.3, c = 0.3, d = 0.3;
+  bool logl = false, batch = true, binary_data = false, bias = false, hier = false, vb = true;
+  // flags that are parsed (they are part of the CLI) but select code that is
+  // outside the hot path; `unsupported` names the first one seen
+  std::string unsupported;
+  // not part of the reference CLI: device ordinal for the HIP side
+  int device = 0;
+
+  std::string prefix;          // output directory (Env::prefix)
+  FILE *plogf = nullptr;       // param.txt
+  FILE *logf = nullptr;        // infer.log
+
+  // main.cc:99-232.  Returns 0, or 1 for "unknown option" (the reference
+  // asserts there); echo = print the "+ n = ..." lines like the reference.
+  int parse(int argc, char **argv, bool echo, std::string *bad_option);
+  // env.hh:283-369: the directory name
+  std::string make_prefix() const;
+  // env.hh:371-402: mkdir (log.cc:97-118), infer.log, param.txt head.
+  // Returns 0 or -1.
+  int open_output();
+  void close_output();
+  std::string file_str(const std::string &f) const { return prefix + f; }
+  void plog(const std::string &key, double v);
+  void plog(const std::string &key, bool v);
+  void plog(const std::string &key, uint32_t v);
+  void plog(const std::string &key, uint64_t v);
+  void plog(const std::string &key, const std::string &v);
+  void lerr(const char *fmt, ...);      // log.hh:49 (the only live log level)
+};
+
+// ------------------------------------------------------------ Ratings -----
+struct HeldOut {          // std::map<Rating,int> flattened in key order
+  std::vector<uint32_t> u, i;
+  std::vector<int32_t> y;
+};
+
+struct Ratings {
+  uint32_t cap_n = 0, cap_m = 0;      // env.n / env.m at read time
+  bool binary = false;
+  uint32_t rating_threshold = 1;
+  uint32_t n = 0, m = 0;              // registered users / items
+  uint64_t nratings = 0;
+  std::vector<uint32_t> seq2user, seq2item;
+  // CSR in visiting order: users by seq id, items in file order
+  std::vector<int64_t> rowptr;
+  std::vector<uint32_t> col;
+  std::vector<uint8_t> val;           // last-duplicate-wins, uint8 wrap
+  HeldOut validation, test;
+
+  // ratings.cc:42-61 + 63-119.  0 / -1 (cannot open) / -2 (the reference's
+  // "unexpected lines" exit(-1))
+  int read_train(const std::string &path);
+  int read_heldout(const std::string &path, HeldOut *out);
+  // ratings.cc:217-271
+  int write_marginals(const std::string &byusers, const std::string &byitems,
+                      uint32_t *longest_users, uint32_t *longest_items) const;
+
+ // open-addressing id -> seq maps (std::map in the reference; only lookups
+  // and insertion order matter)
+  struct IdMap {
+    std::vector<uint32_t> keys, vals; std::vector<uint8_t> used; uint32_t cnt = 0;
+    IdMap() { rehash(1024); }
+    void rehash(uint32_t cap);
+    bool find(uint32_t key, uint32_t *val) const;
+    void put(uint32_t key, uint32_t val);
+  } user2seq, item2seq;
+
+ private:
+  int read_generic(FILE *f, HeldOut *out);
+  uint32_t input_rating_class(uint32_t v) const;
+  std::vector<uint32_t> tr_u_, tr_i_, tr_y_;   // training triples in file order
+};
+
+// ------------------------------------------------------------ MT19937 -----
+// gsl_rng_mt19937: 2002 init_genrand seeding, seed 0 -> 4357,
+// gsl_rng_uniform = u32 / 2^32
+struct Mt19937 {
+  uint32_t mt[624]; int mti;
+  explicit Mt19937(unsigned long seed = 0) { set(seed); }
+  void set(unsigned long seed);
+  uint32_t next_u32();
+  double uniform() { return next_u32() / 4294967296.0; }
+  unsigned long uniform_int(unsigned long n);
+};
+
+double digamma(double x);      // x > 0, |err| ~ 1e-15 (stands for gsl_sf_psi)
+
+// ---------------------------------------------------------- GammaInit -----
+// Host arrays of the start state, in the layout of hpf_set_state.
+struct GammaState {
+  uint32_t n = 0, m = 0, k = 0; bool hier = false, bias = false;
+  std::vector<double> theta_shape, theta_rate, theta_E, theta_Elog;
+  std::vector<double> beta_shape, beta_rate, beta_E, beta_Elog;
+  std::vector<double> xi_shape, xi_rate, xi_E, xi_Elog;
+  std::vector<double> eta_shape, eta_rate, eta_E, eta_Elog;
+  std::vector<double> ubias_shape, ubias_rate, ubias_E, ubias_Elog;
+  std::vector<double> ibias_shape, ibias_rate, ibias_E, ibias_Elog;
+};
+// hgaprec.cc:153-204 with the RNG already seeded as hgaprec.cc:34-38
+void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hier,
+                      bool bias, GammaState *out);
+// the seed rule of hgaprec.cc:34-38 (+ GSL_RNG_SEED like gsl_rng_env_setup)
+Mt19937 make_rng(double env_seed);
+
+// ------------------------------------------------------------ writers -----
+// D2Array<double>::save / D1Array<double>::save: "seq\tid\tv...\n", %.8f;
+// id = seq2id[row] when row < nids else the row index itself
+int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
+                const uint32_t *seq2id, uint32_t nids);
+int save_vector(const std::string &path, const double *a, uint32_t rows,
+                const uint32_t *seq2id, uint32_t nids);
+
+// ------------------------------------------- held-out series / stopping ---
+// HGAPRec::compute_likelihood bookkeeping (hgaprec.cc:1466-1500)
+struct StopRule {
+  double prev_h = 0.0; uint32_t nh = 0;
+  // returns true when the run must stop; *why as written to max.txt
+  bool update(uint32_t iter, double a, int *why);
+};
+
+}  // namespace hgaprec

@@ -120,40 +120,41 @@ bool choose_cfg(uint32_t ld, int V, int *G, int *R)
 
 // ---- kernel dispatch over the template grid -------------------------------
 template <int G, int R, int V>
-void launch_phi_t(const PhiArgs &a, uint32_t blocks, hipStream_t st)
+void launch_phi_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  hipLaunchKernelGGL((phi_pass_kernel<G, R, V>), dim3(blocks), dim3(256), 0, st, a);
+  if (side == 0) hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 0>), dim3(blocks), dim3(256), 0, st, a);
+  else           hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 1>), dim3(blocks), dim3(256), 0, st, a);
 }
 template <int G, int V>
-bool launch_phi_r(int R, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phi_r(int R, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (R) {
-    case 1: launch_phi_t<G, 1, V>(a, blocks, st); return true;
-    case 2: launch_phi_t<G, 2, V>(a, blocks, st); return true;
-    case 3: launch_phi_t<G, 3, V>(a, blocks, st); return true;
-    case 4: launch_phi_t<G, 4, V>(a, blocks, st); return true;
-    case 5: launch_phi_t<G, 5, V>(a, blocks, st); return true;
-    case 6: launch_phi_t<G, 6, V>(a, blocks, st); return true;
-    case 7: launch_phi_t<G, 7, V>(a, blocks, st); return true;
-    case 8: launch_phi_t<G, 8, V>(a, blocks, st); return true;
+    case 1: launch_phi_t<G, 1, V>(side, a, blocks, st); return true;
+    case 2: launch_phi_t<G, 2, V>(side, a, blocks, st); return true;
+    case 3: launch_phi_t<G, 3, V>(side, a, blocks, st); return true;
+    case 4: launch_phi_t<G, 4, V>(side, a, blocks, st); return true;
+    case 5: launch_phi_t<G, 5, V>(side, a, blocks, st); return true;
+    case 6: launch_phi_t<G, 6, V>(side, a, blocks, st); return true;
+    case 7: launch_phi_t<G, 7, V>(side, a, blocks, st); return true;
+    case 8: launch_phi_t<G, 8, V>(side, a, blocks, st); return true;
   }
   return false;
 }
 template <int V>
-bool launch_phi_g(int G, int R, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phi_g(int G, int R, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_phi_r<4, V>(R, a, blocks, st);
-    case 8:  return launch_phi_r<8, V>(R, a, blocks, st);
-    case 16: return launch_phi_r<16, V>(R, a, blocks, st);
-    case 32: return launch_phi_r<32, V>(R, a, blocks, st);
-    case 64: return launch_phi_r<64, V>(R, a, blocks, st);
+    case 4:  return launch_phi_r<4, V>(R, side, a, blocks, st);
+    case 8:  return launch_phi_r<8, V>(R, side, a, blocks, st);
+    case 16: return launch_phi_r<16, V>(R, side, a, blocks, st);
+    case 32: return launch_phi_r<32, V>(R, side, a, blocks, st);
+    case 64: return launch_phi_r<64, V>(R, side, a, blocks, st);
   }
   return false;
 }
-bool launch_phi(int G, int R, int V, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phi(int G, int R, int V, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  return V == 2 ? launch_phi_g<2>(G, R, a, blocks, st) : launch_phi_g<1>(G, R, a, blocks, st);
+  return V == 2 ? launch_phi_g<2>(G, R, side, a, blocks, st) : launch_phi_g<1>(G, R, side, a, blocks, st);
 }
 
 template <int G>
@@ -326,7 +327,7 @@ int prepare_derived(hpf_handle *h)
     const uint32_t nb = s.sweep_blocks;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, h->stream, s.E, s.rows,
                        h->ld, h->K, s.colsum_part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((h->ld + 63) / 64), dim3(64), 0, h->stream,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
                        s.colsum_part, nb, h->ld, s.colsum);
   }
   int rc = check_launch(h, "prepare_derived");
@@ -342,7 +343,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth)
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
   if (own.nseg) {
     const uint32_t blocks = std::min<uint32_t>((own.nseg + 3) / 4, h->phi_blocks);
-    if (!launch_phi(h->phiG, h->phiR, h->phiV, a, blocks, h->stream)) {
+    if (!launch_phi(h->phiG, h->phiR, h->phiV, &own == &h->it ? 1 : 0, a, blocks, h->stream)) {
       h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
     }
   }
@@ -368,7 +369,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((h->ld + 63) / 64), dim3(64), 0, h->stream,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
                      s.colsum_part, s.sweep_blocks, h->ld, colsum_out);
   return check_launch(h, "row sweep");
 }

@@ -96,7 +96,9 @@ struct PhiArgs {
   uint32_t        ld;       // row stride in doubles (even)
 };
 
-template <int G, int R, int V>
+// SIDE only names the instantiation (0 = user-major pass over CSR, 1 =
+// item-major pass over CSC) so that profilers report the two passes apart.
+template <int G, int R, int V, int SIDE>
 __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 {
   constexpr int NG = 64 / G;             // nonzeros per batch
@@ -375,15 +377,23 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
   }
 }
 
-// out[c] = sum over blocks, in block order (deterministic)
-__global__ void colsum_finalize_kernel(const double *part, uint32_t nblocks,
-                                       uint32_t ld, double *out)
+// out[c] = sum over block partials: one 256-thread block per column, each
+// thread sums a fixed strided subset in order, then a fixed-shape LDS tree --
+// the order depends only on nblocks, so the result is bit-reproducible
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double *part, uint32_t nblocks,
+                                                              uint32_t ld, double *out)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ld) return;
+  __shared__ double red[256];
+  const uint32_t c = blockIdx.x;
   double s = 0.0;
-  for (uint32_t b = 0; b < nblocks; ++b) s += part[(size_t)b * ld + c];
-  out[c] = s;
+  for (uint32_t b = threadIdx.x; b < nblocks; b += 256) s += part[(size_t)b * ld + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = red[0];
 }
 
 // plain column sums of E over rows (used once after hpf_set_state):

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads, exports exactly what include/hpf.h declares,
+and refuses to run without a GPU (no CPU fallback anywhere on the product path)."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+import torch
+
+from hgaprec_amd import capi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_functions():
+    text = (ROOT / "include" / "hpf.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpf_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    for name in header_functions():
+        assert getattr(lib, name) is not None
+    assert lib.hpf_abi_version() == 1
+    assert lib.hpf_strerror(0) == b"ok"
+    assert b"device" in lib.hpf_strerror(-2)
+
+
+def test_config_struct_layout_matches_header():
+    # 12 x 4-byte fields, one pointer, two doubles
+    assert C.sizeof(capi.HpfConfig) == 12 * 4 + 8 + 16
+    assert C.sizeof(capi.HpfTiming) == 24
+
+
+def test_no_oracle_on_the_product_path():
+    """the shipped package and native sources never reference oracle/"""
+    for p in list((ROOT / "hgaprec_amd").rglob("*.py")) + list((ROOT / "hgaprec_amd" / "csrc").rglob("*.*")):
+        if p.suffix in (".py", ".cpp", ".hpp", ".hip", ".h"):
+            t = p.read_text()
+            assert "liborc" not in t and "from oracle" not in t and "import oracle" not in t, p
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
+def test_create_fails_loudly_without_gpu():
+    with pytest.raises(capi.HpfError):
+        capi.Hpf(10, 10, 4)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    d = tmp_path / "data"
+    d.mkdir()
+    for f in ("train.tsv", "validation.tsv", "test.tsv"):
+        (d / f).write_text("1\t1\t3\n2\t1\t4\n1\t2\t5\n")
+    r = subprocess.run([str(ROOT / "hgaprec_amd" / "hgaprec"), "-dir", str(d), "-n", "5", "-m", "5",
+                        "-k", "2", "-hier"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr
+
+
+def test_cli_usage_and_unknown_option(tmp_path):
+    exe = str(ROOT / "hgaprec_amd" / "hgaprec")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("gaprec -dir")
+    r = subprocess.run([exe, "-dir", "x", "-bogus"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "error: unknown option -bogus" in r.stdout
+    r = subprocess.run([exe, "-dir", "x", "-nmf"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "outside the MI355X hot-path build" in r.stderr

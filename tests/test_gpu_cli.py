@@ -1,0 +1,110 @@
+"""-m gpu: the `hgaprec` CLI end to end (TSV in -> output directory) against
+the oracle's end-to-end run on the same files.  Comparison rule of SURVEY.md
+8(c): factor TSVs |a-b| <= 1e-4*|b| + 5e-9 (the 5e-9 absorbs %.8f rounding),
+LL series abs diff <= 1e-6, integer columns exact, seconds column ignored."""
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import make_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+EXE = ROOT / "hgaprec_amd" / "hgaprec"
+
+
+def write_dataset(d, n, m, nnz, seed):
+    rng = np.random.default_rng(seed)
+    rowptr, col, val = make_problem(n, m, nnz, seed)
+    uid = rng.permutation(10 * n)[:n] + 1            # raw ids, not in seq order
+    iid = rng.permutation(10 * m)[:m] + 1
+    u = np.repeat(np.arange(n), np.diff(rowptr))
+    order = rng.permutation(u.size)                   # shuffle the file: seq ids = first-seen order
+    split = rng.random(u.size)
+    d.mkdir(parents=True, exist_ok=True)
+    with open(d / "train.tsv", "w") as ft, open(d / "validation.tsv", "w") as fv, open(d / "test.tsv", "w") as fs:
+        for j in order:
+            line = f"{uid[u[j]]}\t{iid[col[j]]}\t{val[j]}\n"
+            (fv if split[j] < 0.05 else fs if split[j] < 0.15 else ft).write(line)
+
+
+def read_tsv(p):
+    rows = [l.split("\t") for l in Path(p).read_text().splitlines()]
+    ints = np.array([[int(r[0]), int(r[1])] for r in rows])
+    vals = np.array([[float(x) for x in r[2:]] for r in rows])
+    return ints, vals
+
+
+def series(p):
+    out = []
+    for l in Path(p).read_text().splitlines():
+        a = l.split("\t")
+        out.append((int(a[0]), float(a[2]), int(a[3])))
+    return out
+
+
+@pytest.mark.parametrize("flags,K,maxit", [
+    (["-hier"], 5, 20),
+    (["-hier", "-bias"], 8, 12),
+    (["-hier", "-binary-data", "-rating-threshold", "3"], 5, 12),
+    ([], 5, None),                 # vb(): runs until the stop rule fires
+    (["-bias"], 5, None),          # vb_bias()
+    (["-hier"], 100, 6),
+])
+def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
+    n, m = 300, 200
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    hier, bias, binary = "-hier" in flags, "-bias" in flags, "-binary-data" in flags
+    thr = 3 if binary else 1
+    rfreq = 2 if hier else 10
+    args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "7", "-rfreq", str(rfreq)] + flags
+    if maxit is not None:
+        args += ["-max-iterations", str(maxit)]
+    r = subprocess.run([str(EXE)] + args, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = [p for p in tmp_path.iterdir() if p.is_dir() and p.name.startswith(f"n{n}-m{m}-k{K}")]
+    assert len(outs) == 1
+    out = outs[0]
+    exp = "-".join(x for x in [f"n{n}-m{m}-k{K}", "batch", "bin" if binary else "", "bias" if bias else "",
+                               "hier" if hier else "", "vb", "seed7"] if x)
+    assert out.name == exp
+
+    ref = tmp_path / "oracle_out"
+    ref.mkdir()
+    last = orc.run(data, ref, n, m, K, hier=hier, bias=bias, binary=binary, rating_threshold=thr,
+                   rfreq=rfreq, max_iterations=maxit if maxit is not None else 1000, seed=7)
+    assert last >= 0
+
+    for f in ("byusers.tsv", "byitems.tsv"):
+        assert (out / f).read_text() == (ref / f).read_text()
+    for f in ("validation.txt", "test.txt"):
+        a, b = series(out / f), series(ref / f)
+        assert [x[0] for x in a] == [x[0] for x in b], f          # same report iterations (same stop)
+        assert [x[2] for x in a] == [x[2] for x in b]
+        assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    ma, mb = (out / "max.txt").read_text().split("\t"), (ref / "max.txt").read_text().split("\t")
+    assert ma[0] == mb[0] and ma[3] == mb[3] and abs(float(ma[2]) - float(mb[2])) <= 2e-5
+
+    names = (["hbeta", "htheta", "betarate", "thetarate"] if hier else ["beta", "theta"])
+    if bias:
+        names += ["betabias", "thetabias"]
+    for nm in names:
+        for suf in ("", "_shape", "_rate"):
+            ia, va = read_tsv(out / f"{nm}{suf}.tsv")
+            ib, vb = read_tsv(ref / f"{nm}{suf}.tsv")
+            assert np.array_equal(ia, ib), nm + suf
+            assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf
+            assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf   # in practice: print rounding only
+    # files the reference's constructor creates even when they stay empty
+    for f in ("heldout.txt", "logl.txt", "precision.txt", "ndcg.txt", "rmse.txt", "infer.log", "param.txt"):
+        assert (out / f).exists()
+    keys = [l.split(":")[0] for l in (out / "param.txt").read_text().splitlines()]
+    assert keys[:20] == ["n", "k", "t", "test_ratio", "validation_ratio", "seed", "a", "b", "c", "d",
+                         "reportfreq", "vb", "bias", "hier", "nmf", "lda", "wals_l", "wals_C",
+                         "mle_user", "mle_item"]
+    assert keys[20:27] == ["training ratings", "post pruning nusers", "post pruning nitems", "statistics",
+                           "infer n", "test ratings", "validation ratings"]

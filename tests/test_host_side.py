@@ -1,0 +1,230 @@
+"""CPU: the product's C++ host side (libhgaprec_host.so: Env naming, TSV
+reader, MT19937 start state, writers, stop rule) against the reference-made
+golden fixtures and against the oracle's independent restatement."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from hgaprec_amd import hostlib
+from hgaprec_amd.capi import STATE_NAMES
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def unhex(lst):
+    return np.array([float.fromhex(s) for s in lst], dtype=np.float64)
+
+
+def write_tsv(path, triples):
+    with open(path, "w") as f:
+        for u, i, y in triples:
+            f.write(f"{u}\t{i}\t{y}\n")
+
+
+# ---------------------------------------------------------------- Env --------
+def test_prefix_matches_reference_env():
+    d = json.loads((GOLD / "env.json").read_text())
+    for c in d["cases"]:
+        assert hostlib.prefix(c["args"]) == c["prefix"], c["args"]
+
+
+def test_param_txt_head_matches_reference_env(tmp_path):
+    d = json.loads((GOLD / "env.json").read_text())
+    cwd = os.getcwd()
+    try:
+        for k, c in enumerate(d["cases"]):
+            wd = tmp_path / f"c{k}"
+            wd.mkdir()
+            os.chdir(wd)
+            p = hostlib.open_output(c["args"])
+            assert p == c["prefix"]
+            assert (wd / p / "param.txt").read_text() == c["param_txt"]
+            assert sorted(os.listdir(wd / p)) == c["files"]
+    finally:
+        os.chdir(cwd)
+
+
+def test_unknown_option_is_rejected():
+    with pytest.raises(ValueError):
+        hostlib.prefix(["-dir", "x", "-frobnicate"])
+
+
+# ---------------------------------------------------------------- RNG --------
+@pytest.mark.parametrize("seed", [0, 1, 7, 2 ** 31, 12345.9])
+def test_mt19937_stream(orc, seed):
+    got = hostlib.mt_u32(seed, 1500)
+    r = orc.Rng(0)
+    if seed:
+        r = orc.Rng(int(seed))
+    want = np.array([r.u32() for _ in range(1500)], np.uint32)
+    assert np.array_equal(got, want)
+    rs = np.random.RandomState(int(seed) if seed else 4357)
+    assert np.array_equal(got.astype(np.uint64), rs.randint(0, 2 ** 32, size=1500, dtype=np.uint64))
+
+
+def test_gsl_rng_seed_env(monkeypatch):
+    monkeypatch.setenv("GSL_RNG_SEED", "99")
+    a = hostlib.mt_u32(0, 10)
+    monkeypatch.delenv("GSL_RNG_SEED")
+    assert np.array_equal(a, hostlib.mt_u32(99, 10))
+
+
+def test_host_digamma(orc):
+    xs = np.concatenate([np.linspace(0.3, 0.32, 40), np.geomspace(1e-3, 1e7, 200)])
+    got, want = hostlib.digamma(xs), orc.psi(xs)
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 2e-15
+
+
+# --------------------------------------------------------- start state -------
+@pytest.mark.parametrize("hier,bias", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("seed", [0, 7])
+def test_initial_state_matches_oracle(orc, hier, bias, seed):
+    n, m, K = 37, 23, 6
+    st = hostlib.initial_state(seed, n, m, K, hier, bias)
+    M = orc.Model(n, m, K, hier, bias, False)
+    M.initialize(seed)
+    for name in STATE_NAMES:
+        try:
+            want = M.state(name)
+        except KeyError:
+            assert name not in st or st[name].size == 0
+            continue
+        got = st[name]
+        if name.endswith("ELOG"):
+            assert np.max(np.abs(got - want)) < 1e-14, name      # psi: two implementations
+        else:
+            assert np.array_equal(got.reshape(want.shape), want), name   # same MT words, same IEEE ops
+
+
+# -------------------------------------------------------------- reader -------
+def _both_readers(orc, tmp_path, train, valid, test, cap_n, cap_m, binary=False, thr=1):
+    write_tsv(tmp_path / "train.tsv", train)
+    write_tsv(tmp_path / "validation.tsv", valid)
+    write_tsv(tmp_path / "test.tsv", test)
+    H = hostlib.Ratings(cap_n, cap_m, binary, thr)
+    O = orc.Ratings(cap_n, cap_m, binary, thr)
+    assert H.read_train(tmp_path / "train.tsv") == 0
+    assert O.read_train(tmp_path / "train.tsv") == 0
+    for w, name in ((0, "validation.tsv"), (1, "test.tsv")):
+        assert H.read_heldout(tmp_path / name, w) == 0
+        assert O.read_heldout(tmp_path / name, w) == 0
+    return H, O
+
+
+def _assert_same(H, O):
+    assert (H.n, H.m, H.nnz) == (O.n, O.m, O.nnz)
+    for a, b in zip(H.csr(), O.csr()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(H.seq2user(), O.seq2user())
+    assert np.array_equal(H.seq2item(), O.seq2item())
+    for w in (0, 1):
+        for a, b in zip(H.heldout(w), O.heldout(w)):
+            assert np.array_equal(a, b)
+
+
+def test_reader_edge_cases(orc, tmp_path):
+    train = [
+        (50, 900, 3), (10, 901, 5), (50, 901, 0),     # rating 0 dropped
+        (77, 902, 0),                                # user 77 only has a dropped rating: never registered
+        (50, 900, 4),                                # duplicate (u,i): listed twice, last rating wins
+        (10, 900, 300),                              # 300 -> uint8 44
+        (10, 903, 256),                              # 256 -> uint8 0 (kept: class is 256, value wraps)
+        (11, 904, 1), (12, 905, 2), (13, 900, 1),     # ids out of order
+    ]
+    valid = [(50, 903, 2), (99, 900, 1), (10, 999, 1), (50, 903, 5), (12, 900, 0)]  # unseen ids skipped; dup pair
+    test = [(13, 901, 4), (11, 900, 260)]
+    H, O = _both_readers(orc, tmp_path, train, valid, test, 100, 100)
+    _assert_same(H, O)
+    rp, col, val = H.csr()
+    assert H.n == 5 and H.m == 5                            # item 902 only had a dropped rating
+    assert list(H.seq2user()) == [50, 10, 11, 12, 13]
+    assert list(col[rp[0]:rp[1]]) == [0, 0]                  # the duplicate appears twice
+    assert list(val[rp[0]:rp[1]]) == [4, 4]                  # both carry the last rating
+    assert list(val[rp[1]:rp[2]]) == [5, 300 % 256, 0]
+    hu, hi, hy = H.heldout(0)
+    assert list(zip(hu, hi, hy)) == [(0, 2, 5)]              # (50,903) overwritten by the later value
+    tu, ti, ty = H.heldout(1)
+    assert list(zip(tu, ti, ty)) == [(2, 0, 260), (4, 1, 4)]  # map order; int kept, wrapped at use
+
+
+def test_reader_capacity_limits(orc, tmp_path):
+    rng = np.random.default_rng(5)
+    train = [(int(u), int(i), int(y)) for u, i, y in
+             zip(rng.integers(0, 40, 400), rng.integers(0, 30, 400), rng.integers(0, 6, 400))]
+    valid = [(int(u), int(i), int(y)) for u, i, y in
+             zip(rng.integers(0, 45, 60), rng.integers(0, 35, 60), rng.integers(0, 6, 60))]
+    H, O = _both_readers(orc, tmp_path, train, valid, valid[:20], cap_n=15, cap_m=12)
+    _assert_same(H, O)
+    assert H.n == 15 and H.m == 12                       # more distinct ids than -n / -m: skipped
+
+
+def test_reader_binary_and_threshold(orc, tmp_path):
+    rng = np.random.default_rng(6)
+    tr = [(int(u), int(i), int(y)) for u, i, y in
+          zip(rng.integers(0, 30, 300), rng.integers(0, 20, 300), rng.integers(0, 6, 300))]
+    for thr in (1, 4):
+        H, O = _both_readers(orc, tmp_path, tr, tr[:50], tr[50:90], 100, 100, binary=True, thr=thr)
+        _assert_same(H, O)
+        assert set(H.csr()[2].tolist()) <= {1}
+        assert set(H.heldout(0)[2].tolist()) <= {1}
+
+
+def test_reader_whitespace_and_no_trailing_newline(orc, tmp_path):
+    (tmp_path / "train.tsv").write_text("1 2 3\n4\t5\t1\n\n  6\t7   2")
+    H = hostlib.Ratings(10, 10)
+    O = orc.Ratings(10, 10)
+    assert H.read_train(tmp_path / "train.tsv") == 0 and O.read_train(tmp_path / "train.tsv") == 0
+    assert H.nnz == 3 and O.nnz == 3
+    for a, b in zip(H.csr(), O.csr()):
+        assert np.array_equal(a, b)
+
+
+def test_reader_empty_file_is_the_references_error(orc, tmp_path):
+    (tmp_path / "e.tsv").write_text("")
+    assert hostlib.Ratings(5, 5).read_train(tmp_path / "e.tsv") == -2     # "unexpected lines" exit(-1)
+    assert orc.Ratings(5, 5).read_train(tmp_path / "e.tsv") == -1
+    assert hostlib.Ratings(5, 5).read_train(tmp_path / "missing.tsv") == -1
+
+
+def test_marginals_files(orc, tmp_path):
+    rng = np.random.default_rng(8)
+    tr = [(int(u) + 100, int(i) + 500, int(y)) for u, i, y in
+          zip(rng.integers(0, 25, 200), rng.integers(0, 15, 200), rng.integers(1, 6, 200))]
+    H, O = _both_readers(orc, tmp_path, tr, tr[:5], tr[:5], 100, 100)
+    H.write_marginals(tmp_path / "hu.tsv", tmp_path / "hi.tsv")
+    O.write_marginals(tmp_path / "ou.tsv", tmp_path / "oi.tsv")
+    assert (tmp_path / "hu.tsv").read_text() == (tmp_path / "ou.tsv").read_text()
+    assert (tmp_path / "hi.tsv").read_text() == (tmp_path / "oi.tsv").read_text()
+    first = (tmp_path / "hu.tsv").read_text().splitlines()[0].split("\t")
+    assert first[0] == "0" and int(first[1]) == tr[0][0]
+
+
+# ------------------------------------------------------------- writers -------
+def test_writers_match_reference_format(tmp_path):
+    d = json.loads((GOLD / "save.json").read_text())
+    for c in d["cases"]:
+        A = unhex(c["A"]).reshape(c["rows"], c["cols"])
+        ids = np.array(c["ids"], np.uint32)
+        hostlib.save_matrix(tmp_path / "m.tsv", A, ids)
+        hostlib.save_vector(tmp_path / "v.tsv", unhex(c["v"]), ids)
+        assert (tmp_path / "m.tsv").read_text() == c["matrix_tsv"]
+        assert (tmp_path / "v.tsv").read_text() == c["vector_tsv"]
+
+
+# ----------------------------------------------------------- stop rule -------
+def test_stop_rule():
+    # hgaprec.cc:1476-1492: nothing before iter > 30; why=0 on a tiny relative gain,
+    # why=1 after three consecutive decreases (nh > 2)
+    it = np.arange(0, 100, 10)
+    a = np.array([-3.0, -2.5, -2.2, -2.1, -2.0999999, -2.0, -1.9, -1.8, -1.7, -1.6])
+    at, why = hostlib.stop_rule(it, a)
+    assert at == 4 and why[4] == 0 and why[:4] == [-1] * 4
+    a = np.array([-3.0, -2.0, -2.1, -2.2, -2.3, -2.4, -2.5, -2.6, -1.0, -1.0])
+    at, why = hostlib.stop_rule(it, a)
+    assert at == 6 and why[6] == 1              # decreases at iters 40, 50, 60 -> nh = 3
+    a = np.array([-3.0, -2.0, -2.1, -2.2, -2.3, -2.25, -2.4, -2.5, -2.45, -2.6])
+    at, why = hostlib.stop_rule(it, a)
+    assert at == -1                              # an increase resets the counter

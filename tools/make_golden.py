@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.json from the REFERENCE's own code, in this container.
+
+Runs oracle/_ref/refpart -- the GSL-free translation units of the reference
+(matrix.hh, env.hh, log.cc) compiled in place from /root/reference/src by
+oracle/Makefile -- on seeded inputs and stores inputs + outputs.  Doubles are
+stored as hex strings (float.hex) so the fixtures are bit-exact.  The rest of
+the reference needs GSL (absent here), so there are no end-to-end fixtures:
+see DESIGN.md "Oracle".
+
+    python tools/make_golden.py        # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+REFPART = ROOT / "oracle" / "_ref" / "refpart"
+GOLD = ROOT / "tests" / "golden"
+
+
+def hexl(a):
+    return [float(x).hex() for x in np.asarray(a, np.float64).ravel()]
+
+
+def softmax_cases():
+    rng = np.random.default_rng(20260929)
+    recs = []
+    sizes = [1, 2, 3, 5, 7, 20, 22, 50, 100, 102, 200]
+    for n in sizes:
+        for scale, shift in ((1.0, 0.0), (5.0, -10.0), (30.0, -40.0)):
+            x = rng.normal(size=n) * scale + shift
+            y = int(rng.integers(0, 6))
+            recs.append((x, y))
+    # hand-picked: ties, huge spread (underflow of the small terms), zeros
+    recs.append((np.zeros(8), 1))
+    recs.append((np.array([-700.0, 0.0, -1.0]), 3))
+    recs.append((np.array([0.0, -745.0, -800.0, -0.5]), 2))
+    recs.append((np.array([3.0, 3.0, 3.0, 3.0]), 5))
+    recs.append((np.linspace(-60, 5, 100), 4))
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = Path(td) / "in.bin", Path(td) / "out.bin"
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<I", len(recs)))
+            for x, y in recs:
+                f.write(struct.pack("<II", x.size, y))
+                f.write(np.asarray(x, "<f8").tobytes())
+        subprocess.run([str(REFPART), "softmax", str(fin), str(fout)], check=True)
+        raw = np.fromfile(fout, "<f8")
+    out, pos = [], 0
+    for x, y in recs:
+        ls = raw[pos]; phi = raw[pos + 1: pos + 1 + x.size]; pos += 1 + x.size
+        out.append({"x": hexl(x), "y": y, "logsum": float(ls).hex(), "phi": hexl(phi)})
+    return {"source": "D1Array<double>::logsum/lognormalize/scale, /root/reference/src/matrix.hh:367-406",
+            "cases": out}
+
+
+def accumulate_cases():
+    rng = np.random.default_rng(7)
+    cases = []
+    for rows, K, bias in ((6, 5, False), (9, 20, True), (4, 100, True)):
+        width = K + 2 if bias else K
+        nrec = 40
+        recs = [(int(rng.integers(rows)), int(rng.integers(0, 6)), rng.normal(size=width) * 3 - 5)
+                for _ in range(nrec)]
+        with tempfile.TemporaryDirectory() as td:
+            fin, fout = Path(td) / "in.bin", Path(td) / "out.bin"
+            with open(fin, "wb") as f:
+                f.write(struct.pack("<IIII", rows, K, width, nrec))
+                for row, y, x in recs:
+                    f.write(struct.pack("<II", row, y))
+                    f.write(np.asarray(x, "<f8").tobytes())
+            subprocess.run([str(REFPART), "accumulate", str(fin), str(fout)], check=True)
+            Mx = np.fromfile(fout, "<f8")
+        cases.append({"rows": rows, "K": K, "width": width,
+                      "recs": [{"row": r, "y": y, "x": hexl(x)} for r, y, x in recs],
+                      "M": hexl(Mx)})
+    return {"source": "lognormalize + scale + D2Array::add_slice (matrix.hh:1060-1067): adds only the "
+                      "first K entries of a K+2 wide phi; rows start at the 0.3 prior", "cases": cases}
+
+
+def save_cases():
+    rng = np.random.default_rng(3)
+    cases = []
+    for rows, cols, nids in ((5, 4, 5), (6, 1, 3), (3, 7, 0)):
+        A = np.concatenate([rng.gamma(0.3, 1.0, size=(rows, cols)),]).astype(np.float64)
+        A.flat[0] = 1e-9; A.flat[-1] = 123456.789012345
+        v = rng.gamma(2.0, 3.0, size=rows)
+        ids = rng.integers(1, 10 ** 6, size=nids).astype(np.uint32)
+        with tempfile.TemporaryDirectory() as td:
+            fin = Path(td) / "in.bin"
+            with open(fin, "wb") as f:
+                f.write(struct.pack("<III", rows, cols, nids))
+                f.write(ids.astype("<u4").tobytes())
+                f.write(A.astype("<f8").tobytes())
+                f.write(v.astype("<f8").tobytes())
+            subprocess.run([str(REFPART), "save", str(fin), str(Path(td) / "m.tsv"), str(Path(td) / "v.tsv")],
+                           check=True)
+            mt, vt = (Path(td) / "m.tsv").read_text(), (Path(td) / "v.tsv").read_text()
+        cases.append({"rows": rows, "cols": cols, "ids": ids.tolist(), "A": hexl(A), "v": hexl(v),
+                      "matrix_tsv": mt, "vector_tsv": vt})
+    return {"source": "D2Array<double>::save matrix.hh:1140-1166, D1Array<double>::save matrix.hh:725-744",
+            "cases": cases}
+
+
+def env_cases():
+    arglists = [
+        ["-dir", "data/ml", "-n", "300", "-m", "200", "-k", "5", "-hier", "-seed", "7"],
+        ["-dir", "data/ml", "-n", "300", "-m", "200", "-k", "5", "-hier", "-bias", "-rfreq", "1"],
+        ["-dir", "/abs/path", "-n", "6040", "-m", "3681", "-k", "20", "-hier", "-binary-data"],
+        ["-dir", "ml", "-n", "10", "-m", "20", "-k", "3"],
+        ["-dir", "movielens", "-n", "10", "-m", "20", "-k", "3", "-bias", "-label", "run1"],
+        ["-dir", "netflix", "-n", "480189", "-m", "17770", "-k", "200", "-hier", "-bias", "-a", "0.5",
+         "-b", "0.25", "-c", "1", "-d", "2", "-seed", "2147483648"],
+        ["-dir", "9data", "-n", "1", "-m", "1", "-k", "1", "-hier", "-seed", "1234567", "-max-iterations", "50"],
+        ["-dir", "xy", "-n", "1", "-m", "1", "-k", "1", "-hier", "-seed", "0.5"],
+    ]
+    cases = []
+    for args in arglists:
+        with tempfile.TemporaryDirectory() as td:
+            r = subprocess.run([str(REFPART), "env"] + args, cwd=td, check=True, capture_output=True, text=True)
+            prefix = r.stdout.strip().splitlines()[-1]
+            param = (Path(td) / prefix / "param.txt").read_text()
+            files = sorted(os.listdir(Path(td) / prefix))
+        cases.append({"args": args, "prefix": prefix, "param_txt": param, "files": files})
+    return {"source": "Env::Env /root/reference/src/env.hh:216-408 (directory name, param.txt head), "
+                      "Logger::initialize log.cc:9-118", "cases": cases}
+
+
+def main():
+    if not REFPART.exists():
+        sys.exit("oracle/_ref/refpart missing: run `make -C oracle ref` where /root/reference exists")
+    GOLD.mkdir(parents=True, exist_ok=True)
+    for name, fn in (("softmax", softmax_cases), ("accumulate", accumulate_cases),
+                     ("save", save_cases), ("env", env_cases)):
+        (GOLD / f"{name}.json").write_text(json.dumps(fn(), indent=1))
+        print("wrote", GOLD / f"{name}.json")
+
+
+if __name__ == "__main__":
+    main()
