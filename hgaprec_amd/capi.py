@@ -50,7 +50,8 @@ class HpfConfig(C.Structure):
 
 class HpfTiming(C.Structure):
     _fields_ = [
-        ("phi_user_ms", C.c_float), ("phi_item_ms", C.c_float),
+        ("phi_user_ms", C.c_float), ("combine_user_ms", C.c_float),
+        ("phi_item_ms", C.c_float), ("combine_item_ms", C.c_float),
         ("sweep_user_ms", C.c_float), ("sweep_item_ms", C.c_float),
         ("iteration_ms", C.c_float), ("iterations", C.c_uint32),
     ]

@@ -60,9 +60,9 @@ struct hpf_handle {
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
   uint32_t seg_max = 512;
-  uint32_t phi_blocks = 2048;
+  uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
-  hipEvent_t evr[RING][5] = {};
+  hipEvent_t evr[RING][7] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
   uint32_t ev_count = 0;                        // iterations recorded so far
   std::string err;
@@ -336,7 +336,7 @@ int prepare_derived(hpf_handle *h)
   return HPF_OK;
 }
 
-int run_phi(hpf_handle *h, Side &own, Side &oth)
+int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
@@ -347,9 +347,10 @@ int run_phi(hpf_handle *h, Side &own, Side &oth)
       h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
     }
   }
+  HIPCHK(h, hipEventRecord(after_kernel, h->stream));
   if (own.nlong) {
-    const uint32_t blocks = std::min<uint32_t>(own.nlong, 4096);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(128), 0, h->stream,
+    const uint32_t blocks = std::min<uint32_t>((own.nlong + 3) / 4, 16384);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
                        own.longrows, own.nlong, own.partial, own.S, h->ld);
   }
   return check_launch(h, "phi pass");
@@ -380,14 +381,16 @@ int iterate_local(hpf_handle *h)
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
+  // events: 0 start | 1 phi_user kernel done | 2 its combine done |
+  //         3 phi_item kernel done | 4 its combine done | 5 user sweep | 6 item sweep
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  if ((rc = run_phi(h, h->u, h->it))) return rc;           // step A, theta shape sums
-  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  if ((rc = run_phi(h, h->it, h->u))) return rc;           // step A, beta shape sums
+  if ((rc = run_phi(h, h->u, h->it, h->ev[1]))) return rc;   // step A, theta shape sums
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  if ((rc = run_phi(h, h->it, h->u, h->ev[3]))) return rc;   // step A, beta shape sums
+  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
   // steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits d = sum_u E[theta]
   if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
-  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
   return HPF_OK;
 }
 
@@ -396,7 +399,7 @@ int iterate_global(hpf_handle *h)
   int rc;
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
   if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
-  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
   h->ev_count++;
   h->iterations++;
   return HPF_OK;
@@ -454,12 +457,21 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     h->own_stream = true;
   }
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
-    for (int e = 0; e < 5; ++e)
+    for (int e = 0; e < 7; ++e)
       if (hipEventCreate(&h->evr[r][e]) != hipSuccess) return fail(HPF_ERR_HIP);
 
   // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
-  h->phiV = 1;
-  if (!choose_cfg(h->ld, 1, &h->phiG, &h->phiR)) return fail(HPF_ERR_UNSUPPORTED);
+  {
+    // 16-byte loads (V=2) when they pad no worse than 8-byte ones (measured:
+    // C2 phi_user 4.36 ms vs 4.52 ms; the passes are fabric-bound either way)
+    int g1 = 0, r1 = 0, g2 = 0, r2 = 0;
+    const bool ok1 = choose_cfg(h->ld, 1, &g1, &r1), ok2 = choose_cfg(h->ld, 2, &g2, &r2);
+    if (!ok1 && !ok2) return fail(HPF_ERR_UNSUPPORTED);
+    const long w1 = ok1 ? (long)g1 * r1 - (long)h->ld : 1L << 30;
+    const long w2 = ok2 ? (long)g2 * r2 * 2 - (long)h->ld : 1L << 30;
+    if (w2 <= w1) { h->phiG = g2; h->phiR = r2; h->phiV = 2; }
+    else { h->phiG = g1; h->phiR = r1; h->phiV = 1; }
+  }
   if (!choose_cfg(h->ld, 1, &h->swG, &h->swR)) return fail(HPF_ERR_UNSUPPORTED);
   if (const char *e = getenv("HPF_PHI_CFG")) {
     int g = 0, r = 0, v = 0;
@@ -528,7 +540,7 @@ void hpf_destroy(hpf_handle *h)
   if (!h->exch_external) dfree(h->exch);
   dfree(h->logfact);
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
-    for (int e = 0; e < 5; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
+    for (int e = 0; e < 7; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -791,22 +803,21 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
   uint32_t n = std::min<uint32_t>(std::min<uint32_t>(n_last, h->ev_count), hpf_handle::RING);
   if (n == 0) return HPF_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  double acc[5] = {0, 0, 0, 0, 0};
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (uint32_t k = 0; k < n; ++k) {
     hipEvent_t *ev = h->evr[(h->ev_count - 1 - k) % hpf_handle::RING];
-    float ms[5];
-    HIPCHK(h, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    HIPCHK(h, hipEventElapsedTime(&ms[1], ev[1], ev[2]));
-    HIPCHK(h, hipEventElapsedTime(&ms[2], ev[2], ev[3]));
-    HIPCHK(h, hipEventElapsedTime(&ms[3], ev[3], ev[4]));
-    HIPCHK(h, hipEventElapsedTime(&ms[4], ev[0], ev[4]));
-    for (int j = 0; j < 5; ++j) acc[j] += ms[j];
+    float ms[7];
+    for (int j = 0; j < 6; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
+    HIPCHK(h, hipEventElapsedTime(&ms[6], ev[0], ev[6]));
+    for (int j = 0; j < 7; ++j) acc[j] += ms[j];
   }
   out->phi_user_ms = (float)(acc[0] / n);
-  out->phi_item_ms = (float)(acc[1] / n);
-  out->sweep_user_ms = (float)(acc[2] / n);
-  out->sweep_item_ms = (float)(acc[3] / n);
-  out->iteration_ms = (float)(acc[4] / n);
+  out->combine_user_ms = (float)(acc[1] / n);
+  out->phi_item_ms = (float)(acc[2] / n);
+  out->combine_item_ms = (float)(acc[3] / n);
+  out->sweep_user_ms = (float)(acc[4] / n);
+  out->sweep_item_ms = (float)(acc[5] / n);
+  out->iteration_ms = (float)(acc[6] / n);
   return HPF_OK;
 }
 

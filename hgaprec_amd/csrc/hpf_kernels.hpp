@@ -217,16 +217,29 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
   }
 }
 
-// long rows: S[row] = sum over its segments' partials, in segment order
-__global__ void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
-                                        const double *partial, double *S, uint32_t ld)
+// long rows: S[row] = sum over its segments' partials, in segment order.
+// One wave per long row, lane = column (+64, ...); the slot loop is unrolled
+// so that 8 independent loads are in flight per lane, the adds stay in order.
+__global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
+                                                               const double *partial, double *S, uint32_t ld)
 {
-  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t r = wave; r < nrows; r += nwaves) {
     const LongRow lr = rows[r];
-    for (uint32_t c = threadIdx.x; c < ld; c += blockDim.x) {
+    for (uint32_t c = lane; c < ld; c += 64) {
+      const double *p = partial + (size_t)lr.first_slot * ld + c;
       double s = 0.0;
-      for (uint32_t p = 0; p < lr.nslots; ++p)
-        s += partial[(size_t)(lr.first_slot + p) * ld + c];
+      uint32_t q = 0;
+      for (; q + 8 <= lr.nslots; q += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(q + j) * ld];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+      }
+      for (; q < lr.nslots; ++q) s += p[(size_t)q * ld];
       S[(size_t)lr.row * ld + c] = s;
     }
   }

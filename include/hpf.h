@@ -92,12 +92,14 @@ typedef struct {
  * handle's stream around each launch group (in multi-rank use sweep_item_ms
  * also spans the caller's all-reduce between iterate_local and _global) */
 typedef struct {
-  float phi_user_ms;    /* K1a: user-major phi pass (theta shape sums)       */
-  float phi_item_ms;    /* K1b: item-major phi pass (beta shape sums)        */
-  float sweep_user_ms;  /* K2 + K4(xi) + K5(user bias) + K7                  */
-  float sweep_item_ms;  /* K3 + K4(eta) + K5(item bias) + K7                 */
-  float iteration_ms;   /* first launch -> last launch of the iteration      */
-  uint32_t iterations;  /* iterations executed so far                        */
+  float phi_user_ms;     /* K1a: phi_pass_kernel<..,0>, user-major (theta sums) */
+  float combine_user_ms; /*      combine of long user rows                      */
+  float phi_item_ms;     /* K1b: phi_pass_kernel<..,1>, item-major (beta sums)  */
+  float combine_item_ms; /*      combine of long item rows                      */
+  float sweep_user_ms;   /* K2 + K4(xi) + K5(user bias) + K7                    */
+  float sweep_item_ms;   /* K3 + K4(eta) + K5(item bias) + K7                   */
+  float iteration_ms;    /* first launch -> last launch of the iteration        */
+  uint32_t iterations;   /* iterations executed so far                          */
 } hpf_timing;
 
 int  hpf_abi_version(void);
