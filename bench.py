@@ -66,6 +66,11 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n, m, nnz (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
+                         "single-GPU smoke test of the N>1 code path)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -81,11 +86,21 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    # one explicit (non-default) HIP stream carries the kernels AND orders the
+    # all-reduce: torch.distributed synchronises the collective with the
+    # *current* torch stream, so the library must launch on that same stream
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
 
     cfg = dict(synth.CONFIGS[args.config])
     if args.scale != 1.0:
@@ -102,7 +117,6 @@ def main():
     torch.cuda.synchronize()
     log(f"[rank {rank}] generated {n_loc} x {m}, nnz={nnz_loc} in {time.perf_counter() - t0:.1f}s")
 
-    stream = torch.cuda.current_stream(dev)
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
             device=local_rank, stream=stream.cuda_stream, n_ranks=world, rank=rank,
             n_users_total=n_loc * world)
@@ -165,6 +179,18 @@ def main():
     else:
         nnz_total = nnz_loc
 
+    replica_check = None
+    if world > 1:
+        # every rank must hold bit-identical item-side state after the same
+        # all-reduced sums: a cheap end-of-run guard against an ordering race
+        be = D.get_state("BETA_E")
+        cs = torch.tensor([float(be.sum()), float(np.abs(be).max())], dtype=torch.float64, device=dev)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replica_check = "ok" if bool(torch.equal(hi, lo)) and bool(torch.isfinite(hi).all()) else "MISMATCH"
+        del be
+
     tm = D.mean_timing(min(args.steps, 64))
     ab = D.algorithmic_bytes()
     if rank == 0:
@@ -203,6 +229,7 @@ def main():
                 "algorithmic_bytes_per_launch": ab[kern], "avg_launch_ms": kms,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+            "replica_check": replica_check,
             "iteration_algorithmic_GBps": (ab["phi_user"] + ab["phi_item"] + ab["rows"]) / (dt / args.steps) / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:
