@@ -43,6 +43,8 @@ struct Side {
   double bias_rate_add = 0.0;
   uint32_t sweep_blocks = 0;
   bool have_E = false, have_L = false, have_prior = false;
+  bool w_dirty = false;      // L was handed in by hpf_set_state: W must be derived from it
+  bool l_stale = false;      // a sweep ran since L was last valid: rebuild L on export
 };
 
 }  // namespace
@@ -303,6 +305,20 @@ double host_digamma(double x)
   return acc + std::log(x) - 0.5 * xi - s;
 }
 
+// rebuild Elog from shape and the rate the last sweep used (export only)
+int refresh_elog(hpf_handle *h, Side &s)
+{
+  if (!s.l_stale || !s.rows) { s.l_stale = false; return HPF_OK; }
+  const size_t ne = (size_t)s.rows * h->ld;
+  const uint32_t blocks = (uint32_t)std::min<size_t>((ne + 255) / 256, 8192);
+  hipLaunchKernelGGL(elog_kernel, dim3(blocks), dim3(256), 0, h->stream, s.S, s.prior_used,
+                     s.colsum_used, s.L, s.rows, h->ld, h->K, s.bias_col, s.bias_rate_add,
+                     h->cfg.r_prior, h->cfg.hier);
+  int rc = check_launch(h, "elog_kernel");
+  if (!rc) s.l_stale = false;
+  return rc;
+}
+
 int prepare_derived(hpf_handle *h)
 {
   if (!h->derived_dirty) return HPF_OK;
@@ -316,7 +332,8 @@ int prepare_derived(hpf_handle *h)
   }
   Side *sides[2] = {&h->u, &h->it};
   for (Side *s : sides) {
-    if (!s->rows) continue;
+    if (!s->rows || !s->w_dirty) continue;
+    s->w_dirty = false;
     const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
     hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
                        s->rows, h->ld, h->K, s->bias_col, s->junk_col);
@@ -361,7 +378,8 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   // remember what the rate was built from (export of *_rate.tsv)
   HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   SweepArgs a;
-  a.S = s.S; a.E = s.E; a.L = s.L; a.W = s.W;
+  a.S = s.S; a.E = s.E; a.W = s.W;
+  s.l_stale = true;
   a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
   a.colsum_oth = colsum_oth; a.colsum_part = s.colsum_part;
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
@@ -658,6 +676,15 @@ int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t cou
     if (kind == 2) s->have_E = true;
     if (kind == 3) s->have_L = true;
   }
+  if (kind == 3) {                           // Elog of theta/beta or of a bias column
+    if (s->l_stale) {
+      // the rest of L predates the last sweep: rebuild it before patching in the new part
+      int rc2 = refresh_elog(h, *s);
+      if (rc2) return rc2;
+      if ((rc = copy_in(h, dev, h->ld, (uint32_t)col0, host, rows, cols))) return rc;
+    }
+    s->w_dirty = true;
+  }
   if (kind != 0) h->derived_dirty = true;
   return HPF_OK;
 }
@@ -729,6 +756,7 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
     return rc;
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
+  if (kind == 3) { int rc = refresh_elog(h, *s); if (rc) return rc; }
   const double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
   return copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
 }

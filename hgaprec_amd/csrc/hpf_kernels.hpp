@@ -246,19 +246,21 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
 }
 
 // ---------------------------------------------------------------------
-// digamma for x > 0: shift to x >= 10 with psi(x) = psi(x+N) - P'(x)/P(x),
-// P(x) = prod_{j<N}(x+j) (one division instead of N), then the asymptotic
-// series (A&S 6.3.18) through x^-14.  Stands where the reference calls
-// gsl_sf_psi (gpbase.hh:260).  |err| <~ 4e-15 abs on [1e-30, inf).
+// digamma for x > 0, in the split form the sweep needs:
+//     psi(x) = log(xs) - corr ,   exp(psi(x)) = xs * exp(-corr)
+// x < 10 is shifted by exactly 10 with psi(x) = psi(x+10) - P'(x)/P(x),
+// P(x) = prod_{j<10}(x+j) (one division instead of ten), then the asymptotic
+// series (A&S 6.3.18) through x^-14 at xs >= 10.  Stands where the reference
+// calls gsl_sf_psi (gpbase.hh:260).  |err| <~ 4e-15 abs on [1e-30, inf).
 // ---------------------------------------------------------------------
-__device__ __forceinline__ double digamma_pos(double x)
+struct PsiParts { double xs, corr; };
+
+__device__ __forceinline__ PsiParts psi_parts(double x)
 {
   double p = 1.0, dp = 0.0;
+  if (x < 10.0) {
 #pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const bool sh = x < 10.0;
-    const double np = p * x, ndp = fma(dp, x, p);
-    p = sh ? np : p; dp = sh ? ndp : dp; x = sh ? x + 1.0 : x;
+    for (int j = 0; j < 10; ++j) { dp = fma(dp, x, p); p *= x; x += 1.0; }
   }
   const double xi = 1.0 / x, x2 = xi * xi;
   double s = 1.0 / 12.0;
@@ -268,7 +270,16 @@ __device__ __forceinline__ double digamma_pos(double x)
   s = fma(-x2, s, 1.0 / 252.0);
   s = fma(-x2, s, 1.0 / 120.0);
   s = fma(-x2, s, 1.0 / 12.0);
-  return log(x) - 0.5 * xi - x2 * s - dp / p;
+  PsiParts r;
+  r.xs = x;
+  r.corr = fma(x2, s, fma(0.5, xi, dp / p));
+  return r;
+}
+
+__device__ __forceinline__ double digamma_pos(double x)
+{
+  const PsiParts r = psi_parts(x);
+  return log(r.xs) - r.corr;
 }
 
 // ---------------------------------------------------------------------
@@ -278,14 +289,15 @@ __device__ __forceinline__ double digamma_pos(double x)
 //   shape = s_prior + S            (S = raw phi sums; written back as shape)
 //   rate  = prior_rate(row) + colsum_other[k]        k < K
 //           r_prior + n_other_total                   bias column
-//   E = shape/rate ; Elog = psi(shape) - log(rate) ; W = exp(Elog - rowmax)
+//   E = shape/rate
+//   W = exp(Elog)/rowmax = [xs*exp(-corr)/rate] / rowmax   (no log in the loop;
+//       Elog = psi(shape) - log(rate) itself is only exported: elog_kernel)
 //   hier: xi/eta update  E_prior(row) = (s0 + K*s0) / (r0 + sum_k E[row,k])
 //   block partial column sums of E  (-> colsum kernel, fixed order)
 // ---------------------------------------------------------------------
 struct SweepArgs {
   double       *S;          // [rows x ld] in: raw sums, out: shape
   double       *E;          // [rows x ld]
-  double       *L;          // [rows x ld] Elog
   double       *W;          // [rows x ld]
   double       *prior_E;    // [rows] E[xi] / E[eta]: in old, out new (hier)
   double       *prior_used; // [rows] value of prior_E used for this rate
@@ -303,7 +315,6 @@ struct SweepArgs {
 template <int G, int R>
 __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 {
-  constexpr int NG = 64 / G;
   __shared__ double red[4][64 * R];      // per-wave column partials
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane % G, q = lane / G;
@@ -322,44 +333,41 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
   for (uint32_t row = grp; row < a.rows; row += ngrp) {
     const size_t base = (size_t)row * ld;
     const double pr = a.hier ? a.prior_E[row] : a.r_prior;
-    double e[R], l[R];
-    double rmax = -1.0e308, rsum = 0.0;
+    double w[R];
+    double wmax = 0.0, rsum = 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t c = g + G * t;
-      e[t] = 0.0; l[t] = 0.0;
+      w[t] = 0.0;
       if (c < ld) {
         const bool real = c < K, isb = (int32_t)c == a.bias_col;
         const bool junk = (int32_t)c == a.junk_col;
+        double e = 0.0, sh = 0.0;
         if (real || isb) {
-          double sh = a.s_prior + a.S[base + c];
+          sh = a.s_prior + a.S[base + c];
           double rt = real ? pr + cso[t] : a.r_prior + a.bias_rate_add;
           // GPBase::make_nonzero, gpbase.hh:27-44
           sh = (sh > 0.0) ? sh : 1e-30;
           rt = (rt > 0.0) ? rt : 1e-30;
-          e[t] = sh / rt;
-          l[t] = digamma_pos(sh) - log(rt);
-          a.S[base + c] = sh;
-          rmax = fmax(rmax, l[t]);
-          if (real) rsum += e[t];
-        } else {
-          a.S[base + c] = 0.0;
-          if (junk) rmax = fmax(rmax, 0.0);
+          e = sh / rt;
+          const PsiParts ps = psi_parts(sh);
+          w[t] = ps.xs * exp(-ps.corr) / rt;        // exp(psi(shape) - log(rate))
+          if (real) { rsum += e; csum[t] += e; }
+        } else if (junk) {
+          w[t] = 1.0;                               // Elog 0 in the other side's bias slot
         }
+        a.S[base + c] = sh;
+        a.E[base + c] = e;
+        wmax = fmax(wmax, w[t]);
       }
     }
-    rmax = group_max<G>(rmax);
+    wmax = group_max<G>(wmax);
     rsum = group_sum<G>(rsum);
+    const double inv = (wmax > 0.0) ? 1.0 / wmax : 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t c = g + G * t;
-      if (c < ld) {
-        const bool live = c < K || (int32_t)c == a.bias_col || (int32_t)c == a.junk_col;
-        a.E[base + c] = e[t];
-        a.L[base + c] = l[t];
-        a.W[base + c] = live ? exp(l[t] - rmax) : 0.0;
-        if (c < K) csum[t] += e[t];
-      }
+      if (c < ld) a.W[base + c] = w[t] * inv;
     }
     if (a.hier && g == 0) {
       // thetarate/betarate: gpbase.hh:877-889,912-925 via hgaprec.cc:1398-1414
@@ -381,12 +389,32 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     if (G <= 4)  v += __shfl_xor(v, 4, 64);
     if (q == 0) red[wv][g + G * t] = v;
   }
-  (void)NG;
   __syncthreads();
   for (uint32_t c = threadIdx.x; c < ld; c += blockDim.x) {
     double v = 0.0;
     if (c < (uint32_t)(G * R)) v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     a.colsum_part[(size_t)blockIdx.x * ld + c] = (c < K) ? v : 0.0;
+  }
+}
+
+// Elog = psi(shape) - log(rate), materialised on demand for export
+// (gpbase.hh:248-262): rate rebuilt from what the last sweep used
+__global__ void elog_kernel(const double *S, const double *prior_used, const double *colsum_used,
+                            double *L, uint32_t rows, uint32_t ld, uint32_t K, int32_t bias_col,
+                            double bias_rate_add, double r_prior, uint32_t hier)
+{
+  const size_t n = (size_t)rows * ld;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t row = (uint32_t)(e / ld), c = (uint32_t)(e % ld);
+    double l = 0.0;
+    if (c < K || (int32_t)c == bias_col) {
+      const double sh = S[e];
+      double rt = (c < K) ? (hier ? prior_used[row] : r_prior) + colsum_used[c] : r_prior + bias_rate_add;
+      rt = (rt > 0.0) ? rt : 1e-30;
+      l = digamma_pos(sh > 0.0 ? sh : 1e-30) - log(rt);
+    }
+    L[e] = l;
   }
 }
 

@@ -177,3 +177,38 @@ def test_two_logical_ranks_equal_one(orc):
         assert rel_err(D.get_state("BETA_E"), M.state("BETA_E")) < RTOL
         assert rel_err(D.get_state("IBIAS_E"), M.state("IBIAS_E")) < RTOL
         assert rel_err(D.get_state("UBIAS_E"), M.state("UBIAS_E")[a:b]) < RTOL
+
+
+def test_empty_shard_and_empty_rows(orc):
+    # users without any nonzero, items nobody rated
+    from hgaprec_amd.capi import Hpf
+    n, m, K = 50, 40, 6
+    rowptr, col, val = make_problem(n, m, 600, 31)
+    rp = np.concatenate([rowptr, np.full(5, rowptr[-1])]).astype(np.int64)
+    n2, m2 = n + 5, m + 3
+    M = orc.Model(n2, m2, K, True, False, False)
+    M.set_csr(rp, col, val)
+    M.initialize(3)
+    D = Hpf(n2, m2, K)
+    D.upload_csr(rp, col, val)
+    copy_state(M, D, True, False)
+    M.iterate(3)
+    D.iterate(3)
+    for w in compare_states(True, False):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+    assert np.allclose(D.get_state("THETA_SHAPE")[n:], 0.3)     # prior only
+
+
+def test_set_elog_again_mid_run(orc):
+    # re-seeding one side's Elog after sweeps ran (L is rebuilt lazily on the device)
+    M, D = _run_pair(orc, 120, 90, 8, 2500, True, True, False, 2, seed=12)
+    M.iterate(2)
+    D.iterate(2)
+    new = M.state("THETA_ELOG") * 0.5 - 0.1
+    M.set_state("THETA_ELOG", new)
+    D.set_state("THETA_ELOG", new)
+    assert rel_err(D.get_state("UBIAS_ELOG"), M.state("UBIAS_ELOG")) < RTOL   # untouched column survived
+    M.iterate(2)
+    D.iterate(2)
+    for w in compare_states(True, True):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
