@@ -33,7 +33,7 @@ EXPORTS = [
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
     "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
-    "hpf_mean_timing",
+    "hpf_mean_timing", "hpf_elbo",
     "hpf_algorithmic_bytes",
 ]
 
@@ -94,6 +94,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_bind_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.hpf_heldout_ll.argtypes = [vp, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t, dp,
                                    C.POINTER(C.c_uint64)]
+    lib.hpf_elbo.argtypes = [vp, dp]
     lib.hpf_synchronize.argtypes = [vp]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
@@ -222,6 +223,11 @@ class Hpf:
         self._check(self.lib.hpf_heldout_ll(self._h, _ptr(u, C.c_uint32), _ptr(i, C.c_uint32),
                                             _ptr(y, C.c_int32), u.size, C.byref(s), C.byref(c)))
         return s.value, c.value
+
+    def elbo(self) -> float:
+        v = C.c_double()
+        self._check(self.lib.hpf_elbo(self._h, C.byref(v)))
+        return v.value
 
     def synchronize(self):
         self._check(self.lib.hpf_synchronize(self._h))

@@ -7,7 +7,7 @@
 // I/O, the MT19937 start state, the held-out series and its stop rule.
 //
 // Out of scope: ranking / precision evaluation,
-// competitor bridges, -logl; their flags are recognised and refused.
+// competitor bridges; their flags are recognised and refused.
 #include "../../../include/hpf.h"
 #include "hgaprec_host.hpp"
 
@@ -29,7 +29,7 @@ struct Driver {
   Env &env; Ratings &rt; hpf_handle *h = nullptr;
   uint32_t n, m, k, iter = 0;
   time_t start;
-  FILE *vf = nullptr, *tf = nullptr;
+  FILE *vf = nullptr, *tf = nullptr, *af = nullptr;
   StopRule stop;
 
   Driver(Env &e, Ratings &r) : env(e), rt(r), n(r.n), m(r.m), k(e.k), start(time(0)) {}
@@ -51,6 +51,7 @@ struct Driver {
       if (!f) { printf("cannot open heldout file:%s\n", strerror(errno)); exit(-1); }
       if (!strcmp(nm, "/validation.txt")) vf = f;
       else if (!strcmp(nm, "/test.txt")) tf = f;
+      else if (!strcmp(nm, "/logl.txt")) af = f;
       else fclose(f);
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
@@ -197,7 +198,14 @@ struct Driver {
         if (compute_likelihood(true)) exit(0);
         compute_likelihood(false);
         save_model();
-        // compute_precision / compute_itemrank / logl: out of scope
+        // compute_precision / compute_itemrank: out of scope
+        if (env.logl) {                          // HGAPRec::logl, hgaprec.cc:2160-2255
+          double v = 0.0;
+          int rc2 = hpf_elbo(h, &v);
+          if (rc2) die("hpf_elbo", rc2);
+          fprintf(af, "%.5f\n", v);
+          fflush(af);
+        }
       }
       if (g_save_state_now) {
         env.lerr("Saving state at iteration %d duration %d secs", iter, duration());
@@ -230,7 +238,6 @@ int main(int argc, char **argv)
                     "-seed -label -rating-threshold -a -b -c -d)\n", env.unsupported.c_str());
     return 2;
   }
-  if (env.logl) fprintf(stderr, "warning: -logl (ELBO) is not computed by this build; logl.txt stays empty\n");
   if (env.open_output()) { fprintf(stderr, "error: cannot create output directory\n"); abort(); }
 
   Ratings ratings;

@@ -28,6 +28,7 @@ struct Side {
   uint32_t rows = 0;
   double *S = nullptr, *E = nullptr, *L = nullptr, *W = nullptr;
   double *prior_E = nullptr, *prior_used = nullptr, *prior_rate = nullptr;
+  double *prior_elog = nullptr, *prior_elog_used = nullptr;   // Elog xi/eta now / as used by the last rate
   double *colsum = nullptr;       // [ld] sum over this side's rows of E
   double *colsum_used = nullptr;  // [ld] other side's colsum used in the last rate
   double *colsum_part = nullptr;  // [sweep_blocks x ld]
@@ -57,6 +58,7 @@ struct hpf_handle {
   Side u, it;
   double *exch = nullptr; size_t exch_count = 0; bool exch_external = false;
   double *logfact = nullptr;
+  int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ELBO kernel)
   uint64_t nnz = 0;
   bool have_csr = false, derived_dirty = true;
   uint32_t iterations = 0;
@@ -97,6 +99,7 @@ void free_side(Side &s, bool S_external)
   if (!S_external) dfree(s.S);
   dfree(s.E); dfree(s.L); dfree(s.W);
   dfree(s.prior_E); dfree(s.prior_used); dfree(s.prior_rate);
+  dfree(s.prior_elog); dfree(s.prior_elog_used);
   dfree(s.colsum_used); dfree(s.colsum_part);
   dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
   dfree(s.segs); dfree(s.longrows); dfree(s.partial); dfree(s.idx); dfree(s.val);
@@ -381,6 +384,8 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.S = s.S; a.E = s.E; a.W = s.W;
   s.l_stale = true;
   a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
+  a.prior_elog = s.prior_elog; a.prior_elog_used = s.prior_elog_used;
+  a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
   a.colsum_oth = colsum_oth; a.colsum_part = s.colsum_part;
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
@@ -525,6 +530,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if ((rc = dalloc(h, &s->prior_E, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_used, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_rate, s->rows))) return fail(rc);
+    if ((rc = dalloc(h, &s->prior_elog, s->rows))) return fail(rc);
+    if ((rc = dalloc(h, &s->prior_elog_used, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->colsum_used, ld))) return fail(rc);
     if ((rc = dalloc(h, &s->colsum_part, (size_t)s->sweep_blocks * ld))) return fail(rc);
   }
@@ -556,7 +563,7 @@ void hpf_destroy(hpf_handle *h)
   free_side(h->it, true);
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
-  dfree(h->logfact);
+  dfree(h->logfact); dfree(h->rowptr_dev);
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
     for (int e = 0; e < 7; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -616,6 +623,10 @@ int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, co
   int rc;
   if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz))) return rc;
   if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz))) return rc;
+  dfree(h->rowptr_dev); h->rowptr_dev = nullptr;
+  if ((rc = dalloc(h, &h->rowptr_dev, (size_t)n + 1))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->rowptr_dev, rowptr, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nnz = nnz; h->have_csr = true;
   return HPF_OK;
 }
@@ -650,7 +661,7 @@ int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t cou
       case 0: dst = &s->prior_shape_set; break;
       case 1: dst = &s->prior_rate; break;
       case 2: dst = &s->prior_E; s->have_prior = true; break;
-      default: dst = &s->prior_elog_set; break;
+      default: dst = &s->prior_elog; break;
     }
     if (!*dst && (rc = dalloc(h, dst, rows))) return rc;
     HIPCHK(h, hipMemcpyAsync(*dst, host, (size_t)rows * 8, hipMemcpyHostToDevice, h->stream));
@@ -704,20 +715,21 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
       HIPCHK(h, hipStreamSynchronize(h->stream));
       return HPF_OK;
     }
+    if (kind == 3) {                     // Elog: set by the host, then maintained by the sweep
+      HIPCHK(h, hipMemcpyAsync(host, s->prior_elog, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      return HPF_OK;
+    }
     if (h->iterations == 0) {
-      const double *src = kind == 0 ? s->prior_shape_set : s->prior_elog_set;
+      const double *src = s->prior_shape_set;
       if (!src) { h->err = "state was never set"; return HPF_ERR_STATE; }
       HIPCHK(h, hipMemcpyAsync(host, src, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       return HPF_OK;
     }
-    // after a sweep: shape = s0 + K*s0 (gpbase.hh:877-882), Elog = psi(shape) - log(rate)
+    // after a sweep: shape = s0 + K*s0 (gpbase.hh:877-882)
     const double sh = s0 + (double)h->K * s0;
-    if (kind == 0) { for (uint32_t r = 0; r < rows; ++r) host[r] = sh; return HPF_OK; }
-    HIPCHK(h, hipMemcpyAsync(host, s->prior_rate, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const double ps = host_digamma(sh);
-    for (uint32_t r = 0; r < rows; ++r) host[r] = ps - std::log(host[r]);
+    for (uint32_t r = 0; r < rows; ++r) host[r] = sh;
     return HPF_OK;
   }
   if (kind == 1) {                            // rate
@@ -813,6 +825,55 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     *sum_out = s;
   } while (0);
   dfree(du); dfree(di); dfree(dy); dfree(dout);
+  return rc;
+}
+
+int hpf_elbo(hpf_handle *h, double *out)
+{
+  if (!h || !out) return HPF_ERR_INVALID;
+  *out = 0.0;
+  if (!h->have_csr || h->iterations == 0) { h->err = "the ELBO is defined after the first iteration"; return HPF_ERR_STATE; }
+  int rc;
+  if ((rc = refresh_elog(h, h->u))) return rc;
+  if ((rc = refresh_elog(h, h->it))) return rc;
+  const uint32_t nb_nnz = (uint32_t)std::min<uint64_t>((h->nnz + 15) / 16, 8192);
+  const uint32_t nb_g = 1024;
+  double *part = nullptr, *rowptr_dev = nullptr; (void)rowptr_dev;
+  const size_t npart = (size_t)std::max<uint32_t>(nb_nnz, 1) + 2 * nb_g;
+  if ((rc = dalloc(h, &part, npart))) return rc;
+  std::vector<double> hp(npart, 0.0);
+  do {
+    if (h->nnz) {
+      ElboNnzArgs a;
+      a.rowptr = h->rowptr_dev; a.col = h->u.idx; a.val = h->u.val;
+      a.Lt = h->u.L; a.Lb = h->it.L; a.Et = h->u.E; a.Eb = h->it.E;
+      a.partial = part; a.nnz = h->nnz; a.n = h->u.rows; a.ld = h->ld; a.K = h->K; a.C = h->C;
+      a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
+      hipLaunchKernelGGL(elbo_nnz_kernel, dim3(nb_nnz), dim3(256), 0, h->stream, a);
+    }
+    const double s0 = h->cfg.s_prior, ps = s0 + (double)h->K * s0;
+    Side *sides[2] = {&h->u, &h->it};
+    for (int k = 0; k < 2; ++k) {
+      Side &s = *sides[k];
+      if (k == 1 && h->cfg.rank != 0) continue;      // replicated item side: counted once
+      if (!s.rows) continue;
+      ElboGammaArgs g;
+      g.S = s.S; g.E = s.E; g.L = s.L; g.prior_used = s.prior_used; g.prior_elog_used = s.prior_elog_used;
+      g.colsum_used = s.colsum_used; g.prior_E = s.prior_E; g.prior_elog = s.prior_elog; g.prior_rate = s.prior_rate;
+      g.partial = part + nb_nnz + (size_t)k * nb_g; g.rows = s.rows; g.ld = h->ld; g.K = h->K;
+      g.bias_col = s.bias_col; g.bias_rate_add = s.bias_rate_add; g.s_prior = s0; g.r_prior = h->cfg.r_prior;
+      g.lg_s_prior = std::lgamma(s0); g.prior_shape = ps; g.lg_prior_shape = std::lgamma(ps); g.hier = h->cfg.hier;
+      hipLaunchKernelGGL(elbo_gamma_kernel, dim3(nb_g), dim3(256), 0, h->stream, g);
+    }
+    if ((rc = check_launch(h, "elbo"))) break;
+    hipError_t e = hipMemcpyAsync(hp.data(), part, npart * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    double s = 0.0;
+    for (size_t k = 0; k < npart; ++k) s += hp[k];
+    *out = s;
+  } while (0);
+  dfree(part);
   return rc;
 }
 

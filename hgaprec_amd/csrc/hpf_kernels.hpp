@@ -302,6 +302,9 @@ struct SweepArgs {
   double       *prior_E;    // [rows] E[xi] / E[eta]: in old, out new (hier)
   double       *prior_used; // [rows] value of prior_E used for this rate
   double       *prior_rate; // [rows] rate of the xi/eta Gamma after update
+  double       *prior_elog; // [rows] Elog xi/eta: in old, out new
+  double       *prior_elog_used; // [rows] Elog xi/eta that goes with prior_used (ELBO)
+  double        psi_prior_shape; // psi(s0 + K*s0), constant, from the host
   const double *colsum_oth; // [ld]   sum over the other side's rows of E
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
@@ -374,8 +377,10 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
       const double sh = a.s_prior + (double)K * a.s_prior;
       const double rt = a.r_prior + rsum;
       a.prior_used[row] = pr;
+      a.prior_elog_used[row] = a.prior_elog[row];
       a.prior_rate[row] = rt;
       a.prior_E[row] = sh / rt;
+      a.prior_elog[row] = a.psi_prior_shape - log(rt);
     }
   }
 
@@ -518,6 +523,123 @@ __global__ __launch_bounds__(256) void heldout_ll_kernel(LLArgs a)
       a.out[p] = ll;
     }
   }
+}
+
+// ---------------------------------------------------------------------
+// ELBO (HGAPRec::logl, hgaprec.cc:2160-2255), report-time only.
+// Per nonzero the reference adds  sum_k y*sphi_k*(x_k - log sphi_k) - sum_k E_t E_b
+// with sphi = yy*softmax(x), yy = (y > 1 ? y : 1); since
+// x_k - log sphi_k = logsumexp(x) - log yy for every k, the first sum is
+// y*yy*(logsumexp(x) - log yy).  One 16-lane group per nonzero; block partials.
+// ---------------------------------------------------------------------
+struct ElboNnzArgs {
+  const int64_t  *rowptr;   // user CSR row pointers (to find the user of a nonzero)
+  const uint32_t *col;
+  const uint8_t  *val;
+  const double   *Lt, *Lb, *Et, *Eb;
+  double         *partial;  // [gridDim.x]
+  uint64_t        nnz;
+  uint32_t        n, ld, K, C;     // C = live columns (K or K+2)
+  int32_t         ubias_col, ibias_col;
+};
+
+__global__ __launch_bounds__(256) void elbo_nnz_kernel(ElboNnzArgs a)
+{
+  constexpr int G = 16;
+  __shared__ double red[256 / G];
+  const int lane = threadIdx.x & 63, g = lane % G;
+  const uint32_t grp_in_block = threadIdx.x / G;
+  const uint64_t grp = (uint64_t)blockIdx.x * (blockDim.x / G) + grp_in_block;
+  const uint64_t ngrp = (uint64_t)gridDim.x * (blockDim.x / G);
+  double acc = 0.0;
+  for (uint64_t j0 = 0; j0 < a.nnz; j0 += ngrp) {
+    const uint64_t j = j0 + grp;
+    const bool ok = j < a.nnz;
+    uint32_t u = 0, it = 0; double y = 1.0;
+    if (ok) {
+      // user of nonzero j: last row with rowptr[row] <= j
+      uint32_t lo = 0, hi = a.n;
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)a.rowptr[mid] <= j) lo = mid; else hi = mid; }
+      u = lo; it = a.col[j]; y = a.val ? (double)a.val[j] : 1.0;
+    }
+    const double *lt = a.Lt + (size_t)u * a.ld, *lb = a.Lb + (size_t)it * a.ld;
+    const double *et = a.Et + (size_t)u * a.ld, *eb = a.Eb + (size_t)it * a.ld;
+    double mx = -1.0e308, dot = 0.0;
+    for (uint32_t c = g; c < a.C; c += G) mx = fmax(mx, lt[c] + lb[c]);
+    mx = group_max<G>(mx);
+    double se = 0.0;
+    for (uint32_t c = g; c < a.C; c += G) se += exp(lt[c] + lb[c] - mx);
+    for (uint32_t c = g; c < a.K; c += G) dot = fma(et[c], eb[c], dot);
+    se = group_sum<G>(se);
+    dot = group_sum<G>(dot);
+    if (ok && g == 0) {
+      const double yy = (y > 1.0) ? y : 1.0;
+      double v = y * yy * (mx + log(se) - log(yy)) - dot;
+      if (a.ubias_col >= 0) v -= et[a.ubias_col] + eb[a.ibias_col];
+      acc += v;
+    }
+  }
+  if (g == 0) red[grp_in_block] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (uint32_t k = 0; k < blockDim.x / G; ++k) s += red[k];
+    a.partial[blockIdx.x] = s;
+  }
+}
+
+// Gamma terms of one side (compute_elbo_term_helper, gpbase.hh:360-387,717-741)
+// plus, with hier, of its xi/eta array (gpbase.hh:951-969); block partials.
+struct ElboGammaArgs {
+  const double *S, *E, *L;               // [rows x ld] shape, E, Elog
+  const double *prior_used, *prior_elog_used;   // hier: E / Elog of xi (eta) the rate used
+  const double *colsum_used;             // [ld]
+  const double *prior_E, *prior_elog, *prior_rate;   // the xi / eta array itself
+  double       *partial;                 // [gridDim.x]
+  uint32_t      rows, ld, K;
+  int32_t       bias_col;
+  double        bias_rate_add, s_prior, r_prior, lg_s_prior, prior_shape, lg_prior_shape;
+  uint32_t      hier;
+};
+
+__global__ __launch_bounds__(256) void elbo_gamma_kernel(ElboGammaArgs a)
+{
+  __shared__ double red[256];
+  const double s0 = a.s_prior, r0 = a.r_prior, lr0 = log(r0);
+  double acc = 0.0;
+  const size_t n = (size_t)a.rows * a.ld;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t row = (uint32_t)(e / a.ld), c = (uint32_t)(e % a.ld);
+    const bool real = c < a.K, isb = (int32_t)c == a.bias_col;
+    if (real || isb) {
+      const double sh = a.S[e], ev = a.E[e], el = a.L[e];
+      const bool h = real && a.hier;
+      double b = real ? (a.hier ? a.prior_used[row] : r0) + a.colsum_used[c] : r0 + a.bias_rate_add;
+      const double av = (sh > 0.0) ? sh : 1e-30;
+      b = (b > 0.0) ? b : 1e-30;
+      double t = s0 * (h ? a.prior_elog_used[row] : lr0) + (s0 - 1.0) * el;
+      t -= (h ? a.prior_used[row] : r0) * ev + a.lg_s_prior;
+      t -= av * log(b) + (av - 1.0) * el;
+      t += b * ev + lgamma(av);
+      acc += t;
+    }
+    if (a.hier && c == 0) {            // the GPArray element of this row
+      const double av = a.prior_shape, b = a.prior_rate[row], ev = a.prior_E[row], el = a.prior_elog[row];
+      double t = s0 * lr0 + (s0 - 1.0) * el;
+      t -= r0 * ev + a.lg_s_prior;
+      t -= av * log(b) + (av - 1.0) * el;
+      t += b * ev + a.lg_prior_shape;
+      acc += t;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
 }
 
 // materialise the per-element rate matrix for export (htheta_rate.tsv):

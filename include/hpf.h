@@ -157,6 +157,14 @@ int  hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i,
                     const int32_t *y, size_t cnt, double *sum_out,
                     uint64_t *cnt_out);
 
+/* replaces: HGAPRec::logl (hgaprec.cc:2160-2255), the bound written to
+ * logl.txt with -logl: the per-nonzero term over this handle's nonzeros plus
+ * the Gamma terms (gpbase.hh:360-387,717-741,951-969) of the user-side
+ * objects and -- on rank 0 only -- of the replicated item-side objects, so
+ * that the sum over ranks is the reference's value.  Needs >= 1 iteration.
+ * Synchronous. */
+int  hpf_elbo(hpf_handle *h, double *out);
+
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
 /* mean over the last n_last iterations (at most 64 are kept); synchronises */

@@ -398,6 +398,8 @@ typedef struct {
   double sprior, rprior;
   double *scurr, *snext, *rcurr, *rnext, *Ev, *Elogv;
   size_t rsize;
+  int hier;                           /* GPMatrix::_hier (set by set_prior_rate)   */
+  double *hier_rprior, *hier_log_rprior;  /* gpbase.hh:134-136                     */
 } gp;
 
 static void gp_set_to_prior(gp *g)   /* gpbase.hh:149-154,527-532,863-868 */
@@ -417,11 +419,14 @@ static void gp_init(gp *g, uint32_t n, uint32_t k, int global_rate)
   g->scurr = (double *)calloc(ns, 8); g->snext = (double *)calloc(ns, 8);
   g->rcurr = (double *)calloc(nr, 8); g->rnext = (double *)calloc(nr, 8);
   g->Ev = (double *)calloc(ns, 8); g->Elogv = (double *)calloc(ns, 8);
+  g->hier = 0;
+  g->hier_rprior = (double *)calloc(n ? n : 1, 8);
+  g->hier_log_rprior = (double *)calloc(n ? n : 1, 8);
 }
 static void gp_free(gp *g)
 {
   free(g->scurr); free(g->snext); free(g->rcurr); free(g->rnext);
-  free(g->Ev); free(g->Elogv);
+  free(g->Ev); free(g->Elogv); free(g->hier_rprior); free(g->hier_log_rprior);
 }
 
 /* gpbase.hh:27-44 */
@@ -621,16 +626,22 @@ static void iterate_hier(orc_model *M)  /* hgaprec.cc:1340-1414 */
   /* B: hgaprec.cc:1370-1378 */
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->beta, M->tmpK);
-  for (uint32_t n = 0; n < M->n; ++n)            /* set_prior_rate gpbase.hh:163-173 */
+  for (uint32_t n = 0; n < M->n; ++n) {          /* set_prior_rate gpbase.hh:163-173 */
     for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] = M->xi.Ev[n];
+    M->theta.hier_rprior[n] = M->xi.Ev[n]; M->theta.hier_log_rprior[n] = M->xi.Elogv[n];
+  }
+  M->theta.hier = 1;
   for (uint32_t n = 0; n < M->n; ++n)            /* update_rate_next gpbase.hh:218-223 */
     for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] += M->tmpK[k];
   gp_swap(&M->theta); gp_compute_expectations(&M->theta);
   /* C: hgaprec.cc:1380-1386 */
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->theta, M->tmpK);
-  for (uint32_t i = 0; i < M->m; ++i)
+  for (uint32_t i = 0; i < M->m; ++i) {
     for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] = M->eta.Ev[i];
+    M->beta.hier_rprior[i] = M->eta.Ev[i]; M->beta.hier_log_rprior[i] = M->eta.Elogv[i];
+  }
+  M->beta.hier = 1;
   for (uint32_t i = 0; i < M->m; ++i)
     for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] += M->tmpK[k];
   gp_swap(&M->beta); gp_compute_expectations(&M->beta);
@@ -700,6 +711,86 @@ double orc_model_heldout_sum(const orc_model *M, const uint32_t *u,
   double s = .0;
   for (uint64_t a = 0; a < cnt; ++a)       /* yval_t r = i->second: uint8 wrap */
     s += rating_likelihood(M, u[a], i[a], (uint8_t)y[a]);
+  return s;
+}
+
+/* compute_elbo_term_helper: GPMatrix gpbase.hh:360-387, GPMatrixGR 717-741,
+   GPArray 951-969 (k == 1 objects built as GPArray: is_array) */
+static double gp_elbo_term(const gp *g, int is_array)
+{
+  double s = .0;
+  if (is_array) {
+    for (uint32_t n = 0; n < g->n; ++n) {
+      double a, b;
+      make_nonzero(g->scurr[n], g->rcurr[n], &a, &b);
+      s += g->sprior * log(g->rprior) + (g->sprior - 1) * g->Elogv[n];
+      s -= g->rprior * g->Ev[n] + lgamma(g->sprior);
+      s -= a * log(b) + (a - 1) * g->Elogv[n];
+      s += b * g->Ev[n] + lgamma(a);
+    }
+    return s;
+  }
+  for (uint32_t n = 0; n < g->n; ++n) {
+    const double *ev = g->Ev + (size_t)n * g->k, *el = g->Elogv + (size_t)n * g->k;
+    for (uint32_t k = 0; k < g->k; ++k) {
+      if (g->hier && !g->global_rate) {
+        s += g->sprior * g->hier_log_rprior[n] + (g->sprior - 1) * el[k];
+        s -= g->hier_rprior[n] * ev[k] + lgamma(g->sprior);
+      } else {
+        s += g->sprior * log(g->rprior) + (g->sprior - 1) * el[k];
+        s -= g->rprior * ev[k] + lgamma(g->sprior);
+      }
+    }
+    for (uint32_t k = 0; k < g->k; ++k) {
+      double a, b;
+      make_nonzero(g->scurr[(size_t)n * g->k + k],
+                   g->global_rate ? g->rcurr[k] : g->rcurr[(size_t)n * g->k + k], &a, &b);
+      s -= a * log(b) + (a - 1) * el[k];
+      s += b * ev[k] + lgamma(a);
+    }
+  }
+  return s;
+}
+
+/* HGAPRec::logl hgaprec.cc:2160-2255 (gsl_sf_lngamma == lgamma for x > 0) */
+double orc_model_elbo(orc_model *M)
+{
+  const uint32_t K = M->K, x = M->bias ? K + 2 : K;
+  double *phi = M->phi;
+  double s = .0;
+  for (uint32_t n = 0; n < M->n; ++n) {
+    const double *elt = M->theta.Elogv + (size_t)n * K, *et = M->theta.Ev + (size_t)n * K;
+    for (int64_t j = M->rowptr[n]; j < M->rowptr[n + 1]; ++j) {
+      uint32_t m = M->col[j];
+      uint8_t y = M->val ? M->val[j] : 1;
+      const double *elb = M->beta.Elogv + (size_t)m * K, *eb = M->beta.Ev + (size_t)m * K;
+      for (uint32_t k = 0; k < K; ++k) phi[k] = elt[k] + elb[k];
+      if (M->bias) { phi[K] = M->ubias.Elogv[n]; phi[K + 1] = M->ibias.Elogv[m]; }
+      orc_lognormalize(phi, x);
+      if (y > 1)
+        for (uint32_t k = 0; k < x; ++k) phi[k] *= y;
+      double v = .0;
+      for (uint32_t k = 0; k < K; ++k)
+        v += y * phi[k] * (elt[k] + elb[k] - log(phi[k]));
+      s += v;
+      if (M->bias) {
+        s += y * phi[K] * (M->ubias.Elogv[n] - log(phi[K]));
+        s += y * phi[K + 1] * (M->ibias.Elogv[m] - log(phi[K + 1]));
+      }
+      for (uint32_t k = 0; k < K; ++k) s -= et[k] * eb[k];
+      if (M->bias) { s -= M->ubias.Ev[n]; s -= M->ibias.Ev[m]; }
+    }
+  }
+  s += gp_elbo_term(&M->theta, 0);
+  s += gp_elbo_term(&M->beta, 0);
+  if (M->hier) {
+    s += gp_elbo_term(&M->xi, 1);
+    s += gp_elbo_term(&M->eta, 1);
+  }
+  if (M->bias) {                      /* n x 1 GPMatrix objects, _hier never set */
+    s += gp_elbo_term(&M->ubias, 0);
+    s += gp_elbo_term(&M->ibias, 0);
+  }
   return s;
 }
 
@@ -843,6 +934,7 @@ int orc_run(const orc_run_args *a)
   snprintf(p, sizeof p, "%s/validation.txt", a->outdir); FILE *vf = fopen(p, "w");
   snprintf(p, sizeof p, "%s/test.txt", a->outdir);       FILE *tf = fopen(p, "w");
   if (!vf || !tf) return -1;
+  snprintf(p, sizeof p, "%s/logl.txt", a->outdir); FILE *af = fopen(p, "w");
   time_t start = time(0);
   orc_model_initialize(M, a->seed);
 
@@ -876,10 +968,11 @@ int orc_run(const orc_run_args *a)
       }
       if (stopped) break;
       save_model(M, R, a->outdir);
+      if (a->logl && af) { fprintf(af, "%.5f\n", orc_model_elbo(M)); fflush(af); }  /* hgaprec.cc:1426-1427 */
     }
     iter++;
   }
-  fclose(vf); fclose(tf);
+  fclose(vf); fclose(tf); if (af) fclose(af);
   orc_model_free(M); orc_ratings_free(R);
   return (int)iter;
 }

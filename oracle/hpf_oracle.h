@@ -98,6 +98,8 @@ void orc_model_iterate(orc_model *M, int n_iters);
 /* hgaprec.cc:1439-1465 ; y is the int stored in the CountMap */
 double orc_model_heldout_sum(const orc_model *M, const uint32_t *u,
                              const uint32_t *i, const int32_t *y, uint64_t cnt);
+/* HGAPRec::logl hgaprec.cc:2160-2255: the variational bound written to logl.txt */
+double orc_model_elbo(orc_model *M);
 /* state access: row-major doubles; returns element count (0 if absent).
  * For the non-hier model *_RATE is the K-vector. */
 size_t orc_model_state(const orc_model *M, int which, const double **ptr);
@@ -118,6 +120,7 @@ typedef struct {
   uint32_t rfreq;
   uint32_t max_iterations;
   double seed;
+  int logl;                 /* -logl: append the bound to logl.txt at every report */
 } orc_run_args;
 int orc_run(const orc_run_args *a);
 

@@ -33,7 +33,7 @@ class RunArgs(C.Structure):
         ("n", C.c_uint32), ("m", C.c_uint32), ("k", C.c_uint32),
         ("hier", C.c_int), ("bias", C.c_int), ("binary", C.c_int),
         ("rating_threshold", C.c_uint32), ("rfreq", C.c_uint32),
-        ("max_iterations", C.c_uint32), ("seed", C.c_double),
+        ("max_iterations", C.c_uint32), ("seed", C.c_double), ("logl", C.c_int),
     ]
 
 
@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
     L.orc_model_iterate.argtypes = [vp, C.c_int]
     L.orc_model_heldout_sum.argtypes = [vp, u32p, u32p, i32p, C.c_uint64]
     L.orc_model_heldout_sum.restype = C.c_double
+    L.orc_model_elbo.argtypes = [vp]
+    L.orc_model_elbo.restype = C.c_double
     L.orc_model_state.argtypes = [vp, C.c_int, C.POINTER(dp)]
     L.orc_model_state.restype = C.c_size_t
     L.orc_model_set_state.argtypes = [vp, C.c_int, dp, C.c_size_t]
@@ -236,6 +238,9 @@ class Model:
             i.ctypes.data_as(C.POINTER(C.c_uint32)),
             y.ctypes.data_as(C.POINTER(C.c_int32)), u.size)
 
+    def elbo(self):
+        return self.L.orc_model_elbo(self._m)
+
     def _shape(self, which):
         obj, kind = STATE[which] // 4, STATE[which] % 4
         if obj == 0:
@@ -275,9 +280,9 @@ class Model:
 
 
 def run(datadir, outdir, n, m, k, hier=True, bias=False, binary=False,
-        rating_threshold=1, rfreq=10, max_iterations=1000, seed=0.0):
+        rating_threshold=1, rfreq=10, max_iterations=1000, seed=0.0, logl=False):
     a = RunArgs(str(datadir).encode(), str(outdir).encode(), n, m, k, int(hier), int(bias),
-                int(binary), rating_threshold, rfreq, max_iterations, float(seed))
+                int(binary), rating_threshold, rfreq, max_iterations, float(seed), int(logl))
     return lib().orc_run(C.byref(a))
 
 

@@ -53,12 +53,15 @@ def series(p):
     ([], 5, None),                 # vb(): runs until the stop rule fires
     (["-bias"], 5, None),          # vb_bias()
     (["-hier"], 100, 6),
+    (["-hier", "-bias", "-logl"], 6, 8),
+    (["-logl"], 4, None),
 ])
 def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
     n, m = 300, 200
     data = tmp_path / "data"
     write_dataset(data, n, m, 9000, seed=17)
     hier, bias, binary = "-hier" in flags, "-bias" in flags, "-binary-data" in flags
+    logl = "-logl" in flags
     thr = 3 if binary else 1
     rfreq = 2 if hier else 10
     args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "7", "-rfreq", str(rfreq)] + flags
@@ -76,7 +79,7 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
     ref = tmp_path / "oracle_out"
     ref.mkdir()
     last = orc.run(data, ref, n, m, K, hier=hier, bias=bias, binary=binary, rating_threshold=thr,
-                   rfreq=rfreq, max_iterations=maxit if maxit is not None else 1000, seed=7)
+                   rfreq=rfreq, max_iterations=maxit if maxit is not None else 1000, seed=7, logl=logl)
     assert last >= 0
 
     for f in ("byusers.tsv", "byitems.tsv"):
@@ -86,6 +89,10 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
         assert [x[0] for x in a] == [x[0] for x in b], f          # same report iterations (same stop)
         assert [x[2] for x in a] == [x[2] for x in b]
         assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    la = [float(x) for x in (out / "logl.txt").read_text().split()]
+    lb = [float(x) for x in (ref / "logl.txt").read_text().split()]
+    assert len(la) == len(lb) and (len(la) > 0) == logl
+    assert all(abs(x - y) <= 2e-5 + 1e-10 * abs(y) for x, y in zip(la, lb))
     ma, mb = (out / "max.txt").read_text().split("\t"), (ref / "max.txt").read_text().split("\t")
     assert ma[0] == mb[0] and ma[3] == mb[3] and abs(float(ma[2]) - float(mb[2])) <= 2e-5
 

@@ -62,6 +62,8 @@ def test_iterations_match_oracle(orc, K, hier, bias, binary):
         sd, cnt = D.heldout_ll(hu, hi, hy)
         assert cnt == hu.size
         assert abs(sd - so) / hu.size < 1e-9, (it, sd, so)
+        eo, ed = M.elbo(), D.elbo()                  # HGAPRec::logl
+        assert abs(ed - eo) <= 1e-10 * abs(eo), (it, ed, eo)
 
 
 def test_power_law_long_rows_and_singletons(orc):
