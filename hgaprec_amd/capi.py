@@ -33,7 +33,7 @@ EXPORTS = [
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
     "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
-    "hpf_mean_timing", "hpf_elbo",
+    "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
     "hpf_algorithmic_bytes",
 ]
 
@@ -95,6 +95,10 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_heldout_ll.argtypes = [vp, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t, dp,
                                    C.POINTER(C.c_uint64)]
     lib.hpf_elbo.argtypes = [vp, dp]
+    u64p = C.POINTER(C.c_uint64)
+    lib.hpf_scores.argtypes = [vp, u32p, C.c_uint32, dp]
+    lib.hpf_rank_topn.argtypes = [vp, u32p, C.c_uint32, u64p, u32p, C.c_uint32, u32p, dp]
+    lib.hpf_item_ranks.argtypes = [vp, u32p, C.c_uint32, u64p, u32p, u32p, u32p, C.c_uint32, u32p, dp]
     lib.hpf_synchronize.argtypes = [vp]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
@@ -228,6 +232,41 @@ class Hpf:
         v = C.c_double()
         self._check(self.lib.hpf_elbo(self._h, C.byref(v)))
         return v.value
+
+    def scores(self, users) -> np.ndarray:
+        users = np.ascontiguousarray(users, dtype=np.uint32)
+        out = np.empty((users.size, self.n_items), dtype=np.float64)
+        self._check(self.lib.hpf_scores(self._h, _ptr(users, C.c_uint32), users.size, _ptr(out, C.c_double)))
+        return out
+
+    @staticmethod
+    def _mask(mask_ptr, mask_items):
+        if mask_ptr is None:
+            return None, None, None, None
+        mp = np.ascontiguousarray(mask_ptr, dtype=np.uint64)
+        mi = np.ascontiguousarray(mask_items, dtype=np.uint32)
+        return mp, mi, _ptr(mp, C.c_uint64), _ptr(mi, C.c_uint32)
+
+    def rank_topn(self, users, topn=100, mask_ptr=None, mask_items=None):
+        users = np.ascontiguousarray(users, dtype=np.uint32)
+        mp, mi, pmp, pmi = self._mask(mask_ptr, mask_items)
+        items = np.empty((users.size, topn), dtype=np.uint32)
+        sc = np.empty((users.size, topn), dtype=np.float64)
+        self._check(self.lib.hpf_rank_topn(self._h, _ptr(users, C.c_uint32), users.size, pmp, pmi, topn,
+                                           _ptr(items, C.c_uint32), _ptr(sc, C.c_double)))
+        return items, sc
+
+    def item_ranks(self, users, q_sel, q_item, mask_ptr=None, mask_items=None):
+        users = np.ascontiguousarray(users, dtype=np.uint32)
+        q_sel = np.ascontiguousarray(q_sel, dtype=np.uint32)
+        q_item = np.ascontiguousarray(q_item, dtype=np.uint32)
+        mp, mi, pmp, pmi = self._mask(mask_ptr, mask_items)
+        rank = np.empty(q_sel.size, dtype=np.uint32)
+        sc = np.empty(q_sel.size, dtype=np.float64)
+        self._check(self.lib.hpf_item_ranks(self._h, _ptr(users, C.c_uint32), users.size, pmp, pmi,
+                                            _ptr(q_sel, C.c_uint32), _ptr(q_item, C.c_uint32), q_sel.size,
+                                            _ptr(rank, C.c_uint32), _ptr(sc, C.c_double)))
+        return rank, sc
 
     def synchronize(self):
         self._check(self.lib.hpf_synchronize(self._h))

@@ -324,6 +324,24 @@ int Ratings::read_heldout(const std::string &path, HeldOut *out)
   return 0;
 }
 
+int Ratings::read_test_users(const std::string &path, std::vector<uint32_t> *out) const
+{
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  out->clear();
+  Tok tk(f);
+  uint32_t uid = 0;
+  while (!tk.at_eof()) {                         // fscanf(f, "%u\n", &uid) per line
+    if (tk.next_u32(&uid) != 1) break;
+    uint32_t us;
+    if (user2seq.find(uid, &us)) out->push_back(us);
+  }
+  fclose(f);
+  std::sort(out->begin(), out->end());
+  out->erase(std::unique(out->begin(), out->end()), out->end());
+  return 0;
+}
+
 int Ratings::write_marginals(const std::string &byusers, const std::string &byitems,
                              uint32_t *lu, uint32_t *li) const
 {

@@ -74,6 +74,9 @@ struct Ratings {
   // "unexpected lines" exit(-1))
   int read_train(const std::string &path);
   int read_heldout(const std::string &path, HeldOut *out);
+  // ratings.cc:273-292: seq ids (sorted, unique) of the listed users that
+  // appear in the training set.  -1 if the file cannot be opened
+  int read_test_users(const std::string &path, std::vector<uint32_t> *out) const;
   // ratings.cc:217-271
   int write_marginals(const std::string &byusers, const std::string &byitems,
                       uint32_t *longest_users, uint32_t *longest_items) const;

@@ -6,11 +6,12 @@
 // host is what the reference also does outside the hot loop: parsing, TSV
 // I/O, the MT19937 start state, the held-out series and its stop rule.
 //
-// Out of scope: ranking / precision evaluation,
-// competitor bridges; their flags are recognised and refused.
+// Out of scope: competitor bridges, MLE/Canny ablations,
+// -gen-ranking/-msr/-rmse report modes; their flags are recognised and refused.
 #include "../../../include/hpf.h"
 #include "hgaprec_host.hpp"
 
+#include <algorithm>
 #include <cassert>
 #include <csignal>
 #include <cstdlib>
@@ -29,8 +30,11 @@ struct Driver {
   Env &env; Ratings &rt; hpf_handle *h = nullptr;
   uint32_t n, m, k, iter = 0;
   time_t start;
-  FILE *vf = nullptr, *tf = nullptr, *af = nullptr;
+  FILE *vf = nullptr, *tf = nullptr, *af = nullptr, *pf = nullptr;
   StopRule stop;
+  Mt19937 rng;                         // gsl_rng *_r: keeps running after initialize()
+  std::vector<uint32_t> sampled;       // _sampled_users (std::map keys: sorted, unique)
+  std::vector<uint32_t> item_deg;      // _movies[m]->size()
 
   Driver(Env &e, Ratings &r) : env(e), rt(r), n(r.n), m(r.m), k(e.k), start(time(0)) {}
 
@@ -52,6 +56,7 @@ struct Driver {
       if (!strcmp(nm, "/validation.txt")) vf = f;
       else if (!strcmp(nm, "/test.txt")) tf = f;
       else if (!strcmp(nm, "/logl.txt")) af = f;
+      else if (!strcmp(nm, "/precision.txt")) pf = f;
       else fclose(f);
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
@@ -89,7 +94,7 @@ struct Driver {
 
   // HGAPRec::initialize (hgaprec.cc:153-204): MT19937 on the host, state to the device
   void initialize() {
-    Mt19937 rng = make_rng(env.seed);
+    rng = make_rng(env.seed);
     GammaState s;
     initialize_state(rng, n, m, k, env.hier, env.bias, &s);
     auto put = [&](hpf_state w, const std::vector<double> &v) {
@@ -160,7 +165,135 @@ struct Driver {
     }
   }
 
-  void do_on_stop() { save_model(); /* gen_ranking_for_users: out of scope */ }
+  // ---- ranking evaluation: compute_precision / compute_itemrank --------
+  bool test_hit(int v) const {                   // ratings.hh:183-189
+    return env.binary_data ? v >= 1 : (uint32_t)v >= env.rating_threshold;
+  }
+  // rating stored for (user n, item m) in the training set, 0 if absent (Ratings::r)
+  uint32_t train_r(uint32_t n, uint32_t m) const {
+    uint32_t r = 0;                              // duplicates carry the same (last) value
+    for (int64_t j = rt.rowptr[n]; j < rt.rowptr[n + 1]; ++j) if (rt.col[(size_t)j] == m) r = rt.val[(size_t)j];
+    return r;
+  }
+  static size_t lower(const HeldOut &h, uint32_t u, uint32_t i) {
+    size_t lo = 0, hi = h.u.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2;
+      if (h.u[mid] < u || (h.u[mid] == u && h.i[mid] < i)) lo = mid + 1; else hi = mid; }
+    return lo;
+  }
+  // validation items of the sampled users, CSR over `sampled` (is_validation())
+  void build_mask(std::vector<uint64_t> &mptr, std::vector<uint32_t> &mitems) const {
+    mptr.assign(sampled.size() + 1, 0); mitems.clear();
+    for (size_t b = 0; b < sampled.size(); ++b) {
+      for (size_t a = lower(rt.validation, sampled[b], 0); a < rt.validation.u.size() && rt.validation.u[a] == sampled[b]; ++a)
+        mitems.push_back(rt.validation.i[a]);
+      mptr[b + 1] = mitems.size();
+    }
+  }
+
+  void compute_precision(bool save_ranking_file) {          // hgaprec.cc:1703-1848
+    if (iter % 100 == 0 && iter > 0) save_ranking_file = true;
+    FILE *f = save_ranking_file ? fopen(env.file_str("/ranking.tsv").c_str(), "w") : nullptr;
+    if (!save_ranking_file) {                    // hgaprec.cc:1714-1721
+      sampled.clear();
+      do {
+        const uint32_t u = (uint32_t)rng.uniform_int(n);
+        auto it = std::lower_bound(sampled.begin(), sampled.end(), u);
+        if (it == sampled.end() || *it != u) sampled.insert(it, u);
+      } while (sampled.size() < 1000 && sampled.size() < n / 2);
+    }
+    const uint32_t N = 100;                      // _topN_by_user
+    std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
+    build_mask(mptr, mitems);
+    std::vector<uint32_t> items(sampled.size() * N); std::vector<double> scores(sampled.size() * N);
+    int rc = hpf_rank_topn(h, sampled.data(), (uint32_t)sampled.size(), mptr.data(), mitems.data(), N,
+                           items.data(), scores.data());
+    if (rc) die("hpf_rank_topn", rc);
+    double mhits10 = 0, mhits100 = 0; uint32_t total_users = 0;
+    for (size_t b = 0; b < sampled.size(); ++b) {
+      const uint32_t u = sampled[b];
+      uint32_t hits10 = 0, hits100 = 0;
+      for (uint32_t j = 0; j < m && j < N; ++j) {
+        const uint32_t it = items[b * N + j]; const double pred = scores[b * N + j];
+        int v = 0;
+        const size_t a = lower(rt.test, u, it);
+        if (a < rt.test.u.size() && rt.test.u[a] == u && rt.test.i[a] == it) {
+          v = test_hit(rt.test.y[a]) ? 1 : 0;
+          if (j < 10) { if (v > 0) { hits10++; hits100++; } }
+          else if (j < 100) { if (v > 0) hits100++; }
+        }
+        if (f && train_r(u, it) == 0) fprintf(f, "%d\t%d\t%.5f\t%d\n", rt.seq2user[u], rt.seq2item[it], pred, v);
+      }
+      mhits10 += (double)hits10 / 10; mhits100 += (double)hits100 / 100; total_users++;
+    }
+    if (f) fclose(f);
+    fprintf(pf, "%d\t%.5f\t%.5f\n", total_users, (double)mhits10 / total_users, (double)mhits100 / total_users);
+    fflush(pf);
+  }
+
+  void compute_itemrank(bool final) {                       // hgaprec.cc:1606-1701
+    if (iter % 100 == 0 && iter > 0) final = true;
+    if (!final) return;
+    FILE *f = fopen(env.file_str("/itemrank.tsv").c_str(), "w");
+    FILE *itemf = fopen(env.file_str("/meanrank.txt").c_str(), "w");
+    if (!itemf) { printf("cannot open logl file:%s\n", strerror(errno)); exit(-1); }
+    if (item_deg.empty()) { item_deg.assign(m, 0); for (uint32_t c : rt.col) item_deg[c]++; }
+    std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
+    build_mask(mptr, mitems);
+    std::vector<uint32_t> qs, qi;                 // one query per test item that is a hit
+    for (size_t b = 0; b < sampled.size(); ++b)
+      for (size_t a = lower(rt.test, sampled[b], 0); a < rt.test.u.size() && rt.test.u[a] == sampled[b]; ++a)
+        if (test_hit(rt.test.y[a])) { qs.push_back((uint32_t)b); qi.push_back(rt.test.i[a]); }
+    std::vector<uint32_t> rank(qs.size()); std::vector<double> pred(qs.size());
+    int rc = hpf_item_ranks(h, sampled.data(), (uint32_t)sampled.size(), mptr.data(), mitems.data(),
+                            qs.data(), qi.data(), (uint32_t)qs.size(), rank.data(), pred.data());
+    if (rc) die("hpf_item_ranks", rc);
+    double sum_rank = .0, sum_reciprocal_rank = .0; uint32_t total_users = 0;
+    std::vector<uint32_t> ord, seen;
+    for (size_t b = 0, q0 = 0; b < sampled.size(); ++b) {
+      size_t q1 = q0; while (q1 < qs.size() && qs[q1] == b) ++q1;
+      const uint32_t u = sampled[b];
+      // items the reference counts as "ranked": Ratings::r(n,m) == 0
+      seen.clear();
+      for (int64_t j = rt.rowptr[u]; j < rt.rowptr[u + 1]; ++j) if (rt.val[(size_t)j] > 0) seen.push_back(rt.col[(size_t)j]);
+      std::sort(seen.begin(), seen.end());
+      const uint32_t nranked = m - (uint32_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
+      ord.resize(q1 - q0);
+      for (size_t k = 0; k < ord.size(); ++k) ord[k] = (uint32_t)(q0 + k);
+      std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return rank[x] < rank[y]; });
+      double rank_ui = .0, reciprocal_rank_ui = .0; uint32_t ntestitems = 0;
+      for (uint32_t q : ord) {
+        const uint32_t j = rank[q];
+        ntestitems++;
+        fprintf(f, "%d\t%d\t%.5f\t%d\t%d\n", u, qi[q], pred[q], j, item_deg[qi[q]]);
+        rank_ui += (j + 1);
+        reciprocal_rank_ui += 1 / (j + 1);        // integer division, as in the reference
+      }
+      if (ntestitems > 0 && nranked > 0) {
+        sum_rank += (rank_ui / nranked) / ntestitems;
+        sum_reciprocal_rank += reciprocal_rank_ui / ntestitems;
+        total_users++;
+      }
+      q0 = q1;
+    }
+    fclose(f);
+    fprintf(itemf, "%d\t%.5f\t%.5f\n", total_users, (double)sum_rank / total_users,
+            (double)sum_reciprocal_rank / total_users);
+    fclose(itemf);
+  }
+
+  void gen_ranking_for_users() {                            // hgaprec.cc:2087-2112 (load == false)
+    const std::string path = env.datfname + "/test_users.tsv";
+    env.lerr("loading test users from %s", path.c_str());
+    std::vector<uint32_t> ids;
+    if (rt.read_test_users(path, &ids)) { env.lerr("cannot open %s", path.c_str()); return; }
+    sampled = ids;
+    compute_precision(true);
+    compute_itemrank(true);
+    env.lerr("DONE writing ranking.tsv in output directory\n");
+  }
+
+  void do_on_stop() { save_model(); gen_ranking_for_users(); }          // hgaprec.cc:1572-1577
 
   // HGAPRec::compute_likelihood (hgaprec.cc:1439-1501); returns true to stop
   bool compute_likelihood(bool validation) {
@@ -198,7 +331,8 @@ struct Driver {
         if (compute_likelihood(true)) exit(0);
         compute_likelihood(false);
         save_model();
-        // compute_precision / compute_itemrank: out of scope
+        compute_precision(false);
+        if (env.hier || !env.bias) compute_itemrank(false);   // vb_bias() has no itemrank call
         if (env.logl) {                          // HGAPRec::logl, hgaprec.cc:2160-2255
           double v = 0.0;
           int rc2 = hpf_elbo(h, &v);

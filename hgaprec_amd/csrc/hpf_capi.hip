@@ -877,6 +877,141 @@ int hpf_elbo(hpf_handle *h, double *out)
   return rc;
 }
 
+// ---- ranking evaluation ----------------------------------------------------
+namespace {
+struct RankCtx {
+  uint32_t *d_users = nullptr; uint64_t *d_mptr = nullptr; uint32_t *d_mitems = nullptr;
+  double *d_scores = nullptr; uint32_t batch = 0, n_sel = 0;
+  ~RankCtx() { dfree(d_users); dfree(d_mptr); dfree(d_mitems); dfree(d_scores); }
+};
+
+int rank_prepare(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const uint64_t *mask_ptr,
+                 const uint32_t *mask_items, RankCtx &c)
+{
+  if (h->iterations == 0 && !(h->u.have_E && h->it.have_E)) { h->err = "E state not set"; return HPF_ERR_STATE; }
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  const uint32_t m = h->it.rows;
+  for (uint32_t b = 0; b < n_sel; ++b)
+    if (users[b] >= h->u.rows) { h->err = "user index out of range"; return HPF_ERR_INVALID; }
+  const uint64_t nmask = mask_ptr ? mask_ptr[n_sel] : 0;
+  if (mask_ptr) {
+    if (mask_ptr[0] != 0) { h->err = "mask_ptr[0] must be 0"; return HPF_ERR_INVALID; }
+    for (uint32_t b = 0; b < n_sel; ++b) if (mask_ptr[b + 1] < mask_ptr[b]) { h->err = "mask_ptr not monotone"; return HPF_ERR_INVALID; }
+    if (nmask && !mask_items) return HPF_ERR_INVALID;
+    for (uint64_t j = 0; j < nmask; ++j) if (mask_items[j] >= m) { h->err = "mask item out of range"; return HPF_ERR_INVALID; }
+  }
+  int rc;
+  c.n_sel = n_sel;
+  // rows of scores kept at once: <= 1 GiB, a multiple of 16
+  uint64_t bmax = ((1ull << 30) / (8ull * std::max<uint32_t>(m, 1))) & ~15ull;
+  bmax = std::max<uint64_t>(bmax, 16);
+  c.batch = (uint32_t)std::min<uint64_t>(bmax, ((uint64_t)n_sel + 15) & ~15ull);
+  if ((rc = dalloc(h, &c.d_users, n_sel))) return rc;
+  if ((rc = dalloc(h, &c.d_scores, (size_t)c.batch * m))) return rc;
+  HIPCHK(h, hipMemcpyAsync(c.d_users, users, (size_t)n_sel * 4, hipMemcpyHostToDevice, h->stream));
+  if (mask_ptr) {
+    if ((rc = dalloc(h, &c.d_mptr, (size_t)n_sel + 1))) return rc;
+    if ((rc = dalloc(h, &c.d_mitems, (size_t)nmask))) return rc;
+    HIPCHK(h, hipMemcpyAsync(c.d_mptr, mask_ptr, ((size_t)n_sel + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    if (nmask) HIPCHK(h, hipMemcpyAsync(c.d_mitems, mask_items, (size_t)nmask * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
+// scores (+ mask) of selected rows [b0, b1) into c.d_scores
+int rank_scores(hpf_handle *h, RankCtx &c, uint32_t b0, uint32_t b1, bool mask)
+{
+  const uint32_t m = h->it.rows, rows = b1 - b0;
+  ScoreArgs a;
+  a.users = c.d_users + b0; a.Et = h->u.E; a.Eb = h->it.E; a.scores = c.d_scores;
+  a.n_sel = rows; a.m = m; a.ld = h->ld; a.K = h->K;
+  a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
+  hipLaunchKernelGGL(score_tile_kernel, dim3((m + 255) / 256, (rows + 15) / 16), dim3(256), 0, h->stream, a);
+  if (mask)
+    hipLaunchKernelGGL(mask_scores_kernel, dim3(std::min<uint32_t>((rows + 3) / 4, 4096)), dim3(256), 0,
+                       h->stream, c.d_users + b0, rows, h->rowptr_dev, h->u.idx, h->u.val,
+                       c.d_mptr ? c.d_mptr + b0 : nullptr, c.d_mitems, c.d_scores, m);
+  return check_launch(h, "score/mask");
+}
+}  // namespace
+
+int hpf_scores(hpf_handle *h, const uint32_t *users, uint32_t n_sel, double *out)
+{
+  if (!h || (n_sel && (!users || !out))) return HPF_ERR_INVALID;
+  if (!n_sel) return HPF_OK;
+  RankCtx c; int rc;
+  if ((rc = rank_prepare(h, users, n_sel, nullptr, nullptr, c))) return rc;
+  const uint32_t m = h->it.rows;
+  for (uint32_t b0 = 0; b0 < n_sel; b0 += c.batch) {
+    const uint32_t b1 = std::min(n_sel, b0 + c.batch);
+    if ((rc = rank_scores(h, c, b0, b1, false))) return rc;
+    HIPCHK(h, hipMemcpyAsync(out + (size_t)b0 * m, c.d_scores, (size_t)(b1 - b0) * m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return HPF_OK;
+}
+
+int hpf_rank_topn(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const uint64_t *mask_ptr,
+                  const uint32_t *mask_items, uint32_t topn, uint32_t *out_items, double *out_scores)
+{
+  if (!h || topn == 0 || topn > 1024 || (n_sel && (!users || !out_items || !out_scores))) return HPF_ERR_INVALID;
+  if (!n_sel) return HPF_OK;
+  RankCtx c; int rc;
+  if ((rc = rank_prepare(h, users, n_sel, mask_ptr, mask_items, c))) return rc;
+  uint32_t NP = 1; while (NP < topn) NP <<= 1;
+  uint32_t *d_items = nullptr; double *d_sc = nullptr;
+  if ((rc = dalloc(h, &d_items, (size_t)n_sel * topn)) || (rc = dalloc(h, &d_sc, (size_t)n_sel * topn))) { dfree(d_items); return rc; }
+  for (uint32_t b0 = 0; b0 < n_sel && !rc; b0 += c.batch) {
+    const uint32_t b1 = std::min(n_sel, b0 + c.batch);
+    if ((rc = rank_scores(h, c, b0, b1, true))) break;
+    hipLaunchKernelGGL(topn_kernel, dim3(b1 - b0), dim3(256), (size_t)NP * 12, h->stream, c.d_scores, b1 - b0,
+                       h->it.rows, topn, NP, d_items + (size_t)b0 * topn, d_sc + (size_t)b0 * topn);
+    rc = check_launch(h, "topn_kernel");
+  }
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(out_items, d_items, (size_t)n_sel * topn * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n_sel * topn * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; }
+  }
+  dfree(d_items); dfree(d_sc);
+  return rc;
+}
+
+int hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const uint64_t *mask_ptr,
+                   const uint32_t *mask_items, const uint32_t *q_sel, const uint32_t *q_item, uint32_t nq,
+                   uint32_t *out_rank, double *out_score)
+{
+  if (!h || (n_sel && !users) || (nq && (!q_sel || !q_item || !out_rank || !out_score))) return HPF_ERR_INVALID;
+  if (!nq) return HPF_OK;
+  for (uint32_t q = 0; q < nq; ++q)
+    if (q_sel[q] >= n_sel || q_item[q] >= h->it.rows) { h->err = "query out of range"; return HPF_ERR_INVALID; }
+  RankCtx c; int rc;
+  if ((rc = rank_prepare(h, users, n_sel, mask_ptr, mask_items, c))) return rc;
+  uint32_t *d_qs = nullptr, *d_qi = nullptr, *d_rank = nullptr; double *d_sc = nullptr;
+  do {
+    if ((rc = dalloc(h, &d_qs, nq)) || (rc = dalloc(h, &d_qi, nq)) || (rc = dalloc(h, &d_rank, nq)) || (rc = dalloc(h, &d_sc, nq))) break;
+    hipError_t e = hipMemcpyAsync(d_qs, q_sel, (size_t)nq * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_qi, q_item, (size_t)nq * 4, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    for (uint32_t b0 = 0; b0 < n_sel && !rc; b0 += c.batch) {
+      const uint32_t b1 = std::min(n_sel, b0 + c.batch);
+      if ((rc = rank_scores(h, c, b0, b1, true))) break;
+      hipLaunchKernelGGL(rank_query_kernel, dim3(std::min<uint32_t>(nq, 16384)), dim3(256), 0, h->stream, c.d_scores,
+                         h->it.rows, d_qs, d_qi, nq, b0, b1, d_rank, d_sc);
+      rc = check_launch(h, "rank_query_kernel");
+    }
+    if (rc) break;
+    e = hipMemcpyAsync(out_rank, d_rank, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_score, d_sc, (size_t)nq * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; }
+  } while (0);
+  dfree(d_qs); dfree(d_qi); dfree(d_rank); dfree(d_sc);
+  return rc;
+}
+
 int hpf_synchronize(hpf_handle *h)
 {
   if (!h) return HPF_ERR_INVALID;

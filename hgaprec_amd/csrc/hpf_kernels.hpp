@@ -642,6 +642,218 @@ __global__ __launch_bounds__(256) void elbo_gamma_kernel(ElboGammaArgs a)
   if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------
+// Ranking evaluation (report steps): compute_precision / compute_itemrank
+// (hgaprec.cc:1703-1848, 1606-1701).  The reference scores EVERY item for each
+// sampled user (prediction_score_hier, hgaprec.cc:1966-1991), zeroes training
+// and validation items, qsorts all m scores and walks the top 100.  Here:
+//   score_tile_kernel   dense E_theta[sel] x E_beta^T on the fp64 matrix cores
+//                       (v_mfma_f64_16x16x4_f64) -- the one GEMM-shaped piece
+//   mask_scores_kernel  training (rating > 0) and validation items -> 0.0
+//   topn_kernel         exact top-N per user: 8-pass radix select on the
+//                       64-bit score pattern, ties by ascending item index
+//                       (= glibc's stable merge-sort qsort), bitonic sort of N
+//   rank_query_kernel   position of one item in the full order (itemrank)
+// ---------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct ScoreArgs {
+  const uint32_t *users;    // [n_sel] selected user rows
+  const double   *Et, *Eb;  // [n x ld], [m x ld]
+  double         *scores;   // [n_sel x m]
+  uint32_t        n_sel, m, ld, K;
+  int32_t         ubias_col, ibias_col;
+};
+
+// block = 4 waves; wave w: 16 users x 64 items (4 MFMA tiles of 16x16)
+__global__ __launch_bounds__(256) void score_tile_kernel(ScoreArgs a)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const uint32_t u0 = blockIdx.y * 16, i0 = (blockIdx.x * 4 + wv) * 64;
+  if (i0 >= a.m) return;
+  const uint32_t usel = u0 + r16;
+  const uint32_t urow = usel < a.n_sel ? a.users[usel] : 0u;
+  const double *pa = a.Et + (size_t)urow * a.ld;
+  const double *pb[4]; bool okb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t it = i0 + 16 * t + r16;
+    okb[t] = it < a.m;
+    pb[t] = a.Eb + (size_t)(okb[t] ? it : 0u) * a.ld;
+  }
+  double4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (uint32_t k0 = 0; k0 < a.K; k0 += 4) {
+    const uint32_t k = k0 + kq;
+    const bool okk = k < a.K;
+    const double av = (okk && usel < a.n_sel) ? pa[k] : 0.0;       // A[i = lane%16][k = lane/16]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double bv = (okk && okb[t]) ? pb[t][k] : 0.0;         // B[k = lane/16][j = lane%16]
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+  // D (4 doubles per lane): register r holds D[i = lane/16 + 4*r][j = lane%16]
+  // (verified against a dense product in tests/test_gpu_ranking.py)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t it = i0 + 16 * t + r16;
+    if (it >= a.m) continue;
+    const double bi = a.ibias_col >= 0 ? a.Eb[(size_t)it * a.ld + a.ibias_col] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t us = u0 + kq + 4 * r;
+      if (us >= a.n_sel) continue;
+      double v = acc[t][r];
+      if (a.ubias_col >= 0) v += a.Et[(size_t)a.users[us] * a.ld + a.ubias_col] + bi;   // s += Eb_u + Eb_i
+      a.scores[(size_t)us * a.m + it] = v;
+    }
+  }
+}
+
+// one wave per selected user: zero the scores of training items with a stored
+// rating > 0 (a uint8-wrapped 0 is NOT skipped: "_ratings.r(n,m) > 0") and of
+// the caller's mask list (validation items)
+__global__ void mask_scores_kernel(const uint32_t *users, uint32_t n_sel, const int64_t *rowptr,
+                                   const uint32_t *col, const uint8_t *val, const uint64_t *mask_ptr,
+                                   const uint32_t *mask_items, double *scores, uint32_t m)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t b = wave; b < n_sel; b += nwaves) {
+    const uint32_t u = users[b];
+    double *row = scores + (size_t)b * m;
+    for (int64_t j = rowptr[u] + lane; j < rowptr[u + 1]; j += 64)
+      if (!val || val[j] > 0) row[col[j]] = 0.0;
+    if (mask_ptr)
+      for (uint64_t j = mask_ptr[b] + lane; j < mask_ptr[b + 1]; j += 64) row[mask_items[j]] = 0.0;
+  }
+}
+
+__device__ __forceinline__ unsigned long long score_key(double v)
+{
+  return (unsigned long long)__double_as_longlong(v);     // scores are >= +0.0: bit order = value order
+}
+
+// exact top-N of one row of scores per block (256 threads); NP = pow2 >= N
+__global__ __launch_bounds__(256) void topn_kernel(const double *scores, uint32_t n_sel, uint32_t m,
+                                                   uint32_t N, uint32_t NP, uint32_t *out_items,
+                                                   double *out_scores)
+{
+  extern __shared__ unsigned char smem[];
+  unsigned long long *ck = (unsigned long long *)smem;            // [NP] candidate keys
+  uint32_t *ci = (uint32_t *)(ck + NP);                          // [NP] candidate items
+  __shared__ uint32_t hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_remaining, s_cnt, s_wtot[4], s_eq_taken;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  if (b >= n_sel) return;
+  const double *row = scores + (size_t)b * m;
+  const uint32_t Ne = N < m ? N : m;
+
+  for (uint32_t k = tid; k < NP; k += 256) { ck[k] = 0ull; ci[k] = 0xffffffffu; }
+  if (tid == 0) { s_prefix = 0ull; s_remaining = Ne; s_cnt = 0; s_eq_taken = 0; }
+  __syncthreads();
+  if (Ne > 0) {
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      hist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      for (uint32_t i = tid; i < m; i += 256) {
+        const unsigned long long key = score_key(row[i]);
+        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, rem = s_remaining; int d = 255;
+        for (; d > 0; --d) { if (cum + hist[d] >= rem) break; cum += hist[d]; }
+        s_remaining = rem - cum;
+        s_prefix = (prefix << 8) | (unsigned long long)d;
+      }
+      __syncthreads();
+    }
+    const unsigned long long T = s_prefix;       // key of the Ne-th largest score
+    const uint32_t need_eq = s_remaining;         // how many of the == T to take (lowest indices)
+    for (uint32_t i = tid; i < m; i += 256) {
+      const unsigned long long key = score_key(row[i]);
+      if (key > T) { const uint32_t p = atomicAdd(&s_cnt, 1u); ck[p] = key; ci[p] = i; }
+    }
+    __syncthreads();
+    const uint32_t base = s_cnt;                  // = Ne - need_eq
+    for (uint32_t c0 = 0; c0 < m; c0 += 256) {    // ties in ascending item order
+      const uint32_t i = c0 + tid;
+      const bool eq = i < m && score_key(row[i]) == T;
+      const unsigned long long bal = __ballot(eq);
+      const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wtot[wv] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      uint32_t woff = 0, tot = 0;
+      for (uint32_t w = 0; w < 4; ++w) { if (w < wv) woff += s_wtot[w]; tot += s_wtot[w]; }
+      const uint32_t taken = s_eq_taken;
+      const uint32_t pos = taken + woff + before;
+      if (eq && pos < need_eq) { ck[base + pos] = T; ci[base + pos] = i; }
+      __syncthreads();
+      if (tid == 0) s_eq_taken = taken + tot;
+      __syncthreads();
+      if (s_eq_taken >= need_eq) break;
+    }
+    __syncthreads();
+    // bitonic sort of NP entries: key descending, item ascending
+    for (uint32_t k = 2; k <= NP; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = tid; t < NP; t += 256) {
+          const uint32_t x = t ^ j;
+          if (x > t) {
+            const bool up = (t & k) == 0;         // "up" block: best entries first
+            const unsigned long long ka = ck[t], kb = ck[x]; const uint32_t ia = ci[t], ib = ci[x];
+            const bool a_first = ka > kb || (ka == kb && ia < ib);
+            if (a_first != up) { ck[t] = kb; ck[x] = ka; ci[t] = ib; ci[x] = ia; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  for (uint32_t k = tid; k < N; k += 256) {
+    out_items[(size_t)b * N + k] = k < Ne ? ci[k] : 0xffffffffu;
+    out_scores[(size_t)b * N + k] = k < Ne ? __longlong_as_double((long long)ck[k]) : 0.0;
+  }
+}
+
+// rank position (0-based) of item q_item[q] in the full descending order of
+// row q_sel[q] (ties by ascending item index); one block per query
+__global__ __launch_bounds__(256) void rank_query_kernel(const double *scores, uint32_t m,
+                                                         const uint32_t *q_sel, const uint32_t *q_item,
+                                                         uint32_t nq, uint32_t sel0, uint32_t sel1,
+                                                         uint32_t *out_rank, double *out_score)
+{
+  __shared__ uint32_t red[256];
+  for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+    const uint32_t b = q_sel[q];
+    if (b < sel0 || b >= sel1) continue;           // not in this batch of rows (uniform per block)
+    const double *row = scores + (size_t)(b - sel0) * m;
+    const uint32_t it = q_item[q];
+    const unsigned long long kq = score_key(row[it]);
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+      const unsigned long long k = score_key(row[i]);
+      c += (k > kq || (k == kq && i < it)) ? 1u : 0u;
+    }
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_rank[q] = red[0]; out_score[q] = row[it]; }
+    __syncthreads();
+  }
+}
+
 // materialise the per-element rate matrix for export (htheta_rate.tsv):
 // rate[row,k] = prior_used[row] + colsum[k]   (gpbase.hh:163-173,218-223)
 __global__ void build_rate_kernel(const double *prior_used, const double *colsum,

@@ -165,6 +165,29 @@ int  hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i,
  * Synchronous. */
 int  hpf_elbo(hpf_handle *h, double *out);
 
+/* ---- ranking evaluation (report steps) ------------------ */
+/* replaces: prediction_score_hier / prediction_score (hgaprec.cc:1966-1991,
+ * 1850-1877; _use_rate_as_score) for every item: out[n_sel x n_items] =
+ * E_theta[users] . E_beta^T (+ biases), on the fp64 matrix cores.  Host out. */
+int  hpf_scores(hpf_handle *h, const uint32_t *users, uint32_t n_sel, double *out);
+/* replaces: the scoring loop, qsort and top-N walk input of
+ * HGAPRec::compute_precision (hgaprec.cc:1722-1765): per selected (local)
+ * user the topn best items in the reference's order -- score descending, ties
+ * by ascending item (glibc's stable qsort) -- after zeroing the user's
+ * training items with a stored rating > 0 and the items of the caller's mask
+ * list (CSR over the selected users; the validation items).  topn <= 1024;
+ * entries beyond n_items are (0xffffffff, 0). */
+int  hpf_rank_topn(hpf_handle *h, const uint32_t *users, uint32_t n_sel,
+                   const uint64_t *mask_ptr, const uint32_t *mask_items, uint32_t topn,
+                   uint32_t *out_items, double *out_scores);
+/* replaces: the position j of a test item in the fully sorted list of
+ * HGAPRec::compute_itemrank (hgaprec.cc:1628-1680): query q asks for item
+ * q_item[q] in the list of selected user q_sel[q] (an index into users). */
+int  hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel,
+                    const uint64_t *mask_ptr, const uint32_t *mask_items,
+                    const uint32_t *q_sel, const uint32_t *q_item, uint32_t nq,
+                    uint32_t *out_rank, double *out_score);
+
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
 /* mean over the last n_last iterations (at most 64 are kept); synchronises */

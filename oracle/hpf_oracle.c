@@ -912,6 +912,203 @@ static void save_model(const orc_model *M, const orc_ratings *R, const char *out
   }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* Ranking evaluation at report steps: compute_precision               */
+/* (hgaprec.cc:1703-1848), compute_itemrank (1606-1701),               */
+/* gen_ranking_for_users (2087-2112), prediction_score[_hier]          */
+/* (1850-1877, 1966-1991; _use_rate_as_score is true, hgaprec.cc:31)    */
+/* ------------------------------------------------------------------ */
+typedef struct { uint32_t first; double second; } orc_kv;   /* std::pair<uint32_t,double>: 16 bytes */
+
+static int cmppairval(const void *p1, const void *p2)        /* matrix.hh:288-293 */
+{
+  const orc_kv *u = (const orc_kv *)p1, *v = (const orc_kv *)p2;
+  return u->second < v->second ? 1 : u->second == v->second ? 0 : -1;
+}
+
+typedef struct {
+  uint32_t *sampled; uint32_t nsampled, cap;    /* _sampled_users (a std::map: sorted keys) */
+  /* per-user scratch rows over the items */
+  uint8_t *train_r;  uint8_t *is_valid;  int32_t *test_v;  uint8_t *has_test;
+  uint32_t *item_deg;
+  orc_kv *mlist;
+} orc_eval;
+
+static int cmp_u32(const void *a, const void *b)
+{ uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+
+static orc_eval *eval_new(const orc_ratings *R)
+{
+  orc_eval *E = (orc_eval *)calloc(1, sizeof(*E));
+  uint32_t m = R->nitems ? R->nitems : 1;
+  E->train_r = (uint8_t *)calloc(m, 1); E->is_valid = (uint8_t *)calloc(m, 1);
+  E->test_v = (int32_t *)calloc(m, 4); E->has_test = (uint8_t *)calloc(m, 1);
+  E->item_deg = (uint32_t *)calloc(m, 4);
+  for (uint64_t j = 0; j < R->ntr; ++j) E->item_deg[R->col[j]]++;     /* _movies[m]->size() */
+  E->mlist = (orc_kv *)malloc(sizeof(orc_kv) * m);
+  return E;
+}
+static void eval_free(orc_eval *E)
+{
+  if (!E) return;
+  free(E->sampled); free(E->train_r); free(E->is_valid); free(E->test_v); free(E->has_test);
+  free(E->item_deg); free(E->mlist); free(E);
+}
+
+/* first index of user n in a (u,i)-sorted held-out list */
+static uint64_t ho_lower(const orc_ratings *R, int w, uint32_t n)
+{
+  uint64_t lo = 0, hi = R->nho[w];
+  while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (R->ho_u[w][mid] < n) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+static void eval_load_user(orc_eval *E, const orc_ratings *R, uint32_t n, int set)
+{
+  for (int64_t j = R->rowptr[n]; j < R->rowptr[n + 1]; ++j) E->train_r[R->col[j]] = set ? R->val[j] : 0;
+  for (uint64_t a = ho_lower(R, 0, n); a < R->nho[0] && R->ho_u[0][a] == n; ++a)
+    E->is_valid[R->ho_i[0][a]] = (uint8_t)set;
+  for (uint64_t a = ho_lower(R, 1, n); a < R->nho[1] && R->ho_u[1][a] == n; ++a) {
+    E->has_test[R->ho_i[1][a]] = (uint8_t)set; E->test_v[R->ho_i[1][a]] = set ? R->ho_y[1][a] : 0;
+  }
+}
+
+static double prediction_score(const orc_model *M, uint32_t user, uint32_t movie)
+{
+  const double *et = M->theta.Ev + (size_t)user * M->K, *eb = M->beta.Ev + (size_t)movie * M->K;
+  double s = .0;
+  for (uint32_t k = 0; k < M->K; ++k) s += et[k] * eb[k];
+  if (M->bias) s += M->ubias.Ev[user] + M->ibias.Ev[movie];
+  return s;                                   /* _use_rate_as_score */
+}
+
+/* ratings.hh:183-189 */
+static int test_hit(const orc_ratings *R, int v)
+{ return R->binary ? v >= 1 : (uint32_t)v >= R->thr; }
+
+static void eval_score_and_sort(orc_eval *E, const orc_model *M, uint32_t n)
+{
+  for (uint32_t m = 0; m < M->m; ++m) {
+    E->mlist[m].first = m;
+    E->mlist[m].second = (E->train_r[m] > 0 || E->is_valid[m]) ? .0 : prediction_score(M, n, m);
+  }
+  qsort(E->mlist, M->m, sizeof(orc_kv), cmppairval);       /* D1Array<KV>::sort_by_value */
+}
+
+static void compute_precision(orc_eval *E, orc_model *M, const orc_ratings *R, uint32_t iter,
+                              int save_ranking_file, FILE *pf, const char *outdir)
+{
+  char p[4096];
+  if (iter % 100 == 0 && iter > 0) save_ranking_file = 1;
+  double mhits10 = 0, mhits100 = 0;
+  uint32_t total_users = 0;
+  FILE *f = NULL;
+  if (save_ranking_file) { snprintf(p, sizeof p, "%s/ranking.tsv", outdir); f = fopen(p, "w"); }
+  if (!save_ranking_file) {                     /* hgaprec.cc:1714-1721 */
+    uint32_t cnt = 0;
+    if (!E->sampled) { E->cap = 1024; E->sampled = (uint32_t *)malloc(4 * E->cap); }
+    do {
+      uint32_t n = (uint32_t)orc_rng_uniform_int(&M->rng, M->n);
+      int seen = 0;
+      for (uint32_t a = 0; a < cnt; ++a) if (E->sampled[a] == n) { seen = 1; break; }
+      if (!seen) E->sampled[cnt++] = n;
+    } while (cnt < 1000 && cnt < M->n / 2);
+    qsort(E->sampled, cnt, 4, cmp_u32);
+    E->nsampled = cnt;
+  }
+  for (uint32_t a = 0; a < E->nsampled; ++a) {
+    uint32_t n = E->sampled[a];
+    eval_load_user(E, R, n, 1);
+    eval_score_and_sort(E, M, n);
+    uint32_t hits10 = 0, hits100 = 0;
+    for (uint32_t j = 0; j < M->m && j < 100; ++j) {          /* _topN_by_user = 100 */
+      uint32_t m = E->mlist[j].first; double pred = E->mlist[j].second;
+      int v = 0;
+      if (E->has_test[m]) {
+        v = test_hit(R, E->test_v[m]) ? 1 : 0;
+        if (j < 10) { if (v > 0) { hits10++; hits100++; } }
+        else if (j < 100) { if (v > 0) hits100++; }
+      }
+      if (save_ranking_file && f && E->train_r[m] == 0)
+        fprintf(f, "%d\t%d\t%.5f\t%d\n", R->seq2user[n], R->seq2item[m], pred, v);
+    }
+    mhits10 += (double)hits10 / 10;
+    mhits100 += (double)hits100 / 100;
+    total_users++;
+    eval_load_user(E, R, n, 0);
+  }
+  if (f) fclose(f);
+  fprintf(pf, "%d\t%.5f\t%.5f\n", total_users, (double)mhits10 / total_users, (double)mhits100 / total_users);
+  fflush(pf);
+}
+
+static void compute_itemrank(orc_eval *E, orc_model *M, const orc_ratings *R, uint32_t iter,
+                             int final, const char *outdir)
+{
+  char p[4096];
+  if (iter % 100 == 0 && iter > 0) final = 1;
+  if (!final) return;
+  uint32_t total_users = 0;
+  snprintf(p, sizeof p, "%s/itemrank.tsv", outdir); FILE *f = fopen(p, "w");
+  snprintf(p, sizeof p, "%s/meanrank.txt", outdir); FILE *itemf = fopen(p, "w");
+  double sum_rank = .0, sum_reciprocal_rank = .0;
+  for (uint32_t a = 0; a < E->nsampled; ++a) {
+    uint32_t n = E->sampled[a];
+    eval_load_user(E, R, n, 1);
+    eval_score_and_sort(E, M, n);
+    double rank_ui = .0, reciprocal_rank_ui = .0;
+    uint32_t ntestitems = 0, nranked = 0;
+    for (uint32_t j = 0; j < M->m; ++j) {
+      uint32_t m = E->mlist[j].first; double pred = E->mlist[j].second;
+      if (E->train_r[m] == 0) nranked++;
+      if (E->has_test[m] && test_hit(R, E->test_v[m])) {
+        ntestitems++;
+        fprintf(f, "%d\t%d\t%.5f\t%d\t%d\n", n, m, pred, j, E->item_deg[m]);
+        rank_ui += (j + 1);
+        reciprocal_rank_ui += 1 / (j + 1);                  /* integer division, as written */
+      }
+    }
+    if (ntestitems > 0 && nranked > 0) {
+      sum_rank += (rank_ui / nranked) / ntestitems;
+      sum_reciprocal_rank += reciprocal_rank_ui / ntestitems;
+      total_users++;
+    }
+    eval_load_user(E, R, n, 0);
+  }
+  fclose(f);
+  fprintf(itemf, "%d\t%.5f\t%.5f\n", total_users, (double)sum_rank / total_users,
+          (double)sum_reciprocal_rank / total_users);
+  fclose(itemf);
+}
+
+/* gen_ranking_for_users(false) hgaprec.cc:2087-2112 + read_test_users ratings.cc:273-292 */
+static void gen_ranking_for_users(orc_eval *E, orc_model *M, const orc_ratings *R, uint32_t iter,
+                                  FILE *pf, const char *datadir, const char *outdir)
+{
+  char p[4096];
+  snprintf(p, sizeof p, "%s/test_users.tsv", datadir);
+  FILE *f = fopen(p, "r");
+  if (!f) return;
+  uint32_t cnt = 0, uid = 0;
+  if (!E->sampled) { E->cap = 1024; E->sampled = (uint32_t *)malloc(4 * E->cap); }
+  while (!feof(f)) {
+    if (fscanf(f, "%u\n", &uid) < 0) break;
+    uint32_t n;
+    if (!idmap_find(&R->user2seq, uid, &n)) continue;
+    int seen = 0;
+    for (uint32_t a = 0; a < cnt; ++a) if (E->sampled[a] == n) { seen = 1; break; }
+    if (seen) continue;
+    if (cnt == E->cap) { E->cap *= 2; E->sampled = (uint32_t *)realloc(E->sampled, 4 * E->cap); }
+    E->sampled[cnt++] = n;
+  }
+  fclose(f);
+  qsort(E->sampled, cnt, 4, cmp_u32);
+  E->nsampled = cnt;
+  compute_precision(E, M, R, iter, 1, pf, outdir);
+  compute_itemrank(E, M, R, iter, 1, outdir);
+}
+
 /* main.cc:234-361 + HGAPRec::vb_hier / vb / vb_bias report logic +
    compute_likelihood hgaprec.cc:1439-1501 (stop rule) */
 int orc_run(const orc_run_args *a)
@@ -935,6 +1132,8 @@ int orc_run(const orc_run_args *a)
   snprintf(p, sizeof p, "%s/test.txt", a->outdir);       FILE *tf = fopen(p, "w");
   if (!vf || !tf) return -1;
   snprintf(p, sizeof p, "%s/logl.txt", a->outdir); FILE *af = fopen(p, "w");
+  snprintf(p, sizeof p, "%s/precision.txt", a->outdir); FILE *pf = fopen(p, "w");
+  orc_eval *E = eval_new(R);
   time_t start = time(0);
   orc_model_initialize(M, a->seed);
 
@@ -964,15 +1163,23 @@ int orc_run(const orc_run_args *a)
         FILE *f = fopen(p, "w");
         fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, (int)(time(0) - start), av, why);
         fclose(f);
-        if (stop) { save_model(M, R, a->outdir); stopped = 1; }  /* do_on_stop; exit(0) */
+        if (stop) {                                /* do_on_stop(); exit(0) */
+          save_model(M, R, a->outdir);
+          gen_ranking_for_users(E, M, R, iter, pf, a->datadir, a->outdir);
+          stopped = 1;
+        }
       }
       if (stopped) break;
       save_model(M, R, a->outdir);
+      compute_precision(E, M, R, iter, 0, pf, a->outdir);
+      if (a->hier || !a->bias)                   /* vb_bias() has no compute_itemrank call */
+        compute_itemrank(E, M, R, iter, 0, a->outdir);
       if (a->logl && af) { fprintf(af, "%.5f\n", orc_model_elbo(M)); fflush(af); }  /* hgaprec.cc:1426-1427 */
     }
     iter++;
   }
-  fclose(vf); fclose(tf); if (af) fclose(af);
+  fclose(vf); fclose(tf); if (af) fclose(af); if (pf) fclose(pf);
+  eval_free(E);
   orc_model_free(M); orc_ratings_free(R);
   return (int)iter;
 }

@@ -55,6 +55,7 @@ def series(p):
     (["-hier"], 100, 6),
     (["-hier", "-bias", "-logl"], 6, 8),
     (["-logl"], 4, None),
+    (["-hier", "-rfreq", "50"], 5, 100),      # iteration 100: ranking.tsv + itemrank.tsv + meanrank.txt
 ])
 def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
     n, m = 300, 200
@@ -64,6 +65,14 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
     logl = "-logl" in flags
     thr = 3 if binary else 1
     rfreq = 2 if hier else 10
+    if "-rfreq" in flags:
+        rfreq = int(flags[flags.index("-rfreq") + 1])
+        flags = [f for k, f in enumerate(flags) if f != "-rfreq" and (k == 0 or flags[k - 1] != "-rfreq")]
+    if not hier:
+        # the batch loops without -hier end through the stop rule -> do_on_stop ->
+        # gen_ranking_for_users, which needs <dir>/test_users.tsv (raw user ids)
+        ids = sorted({int(l.split("\t")[0]) for l in (data / "test.tsv").read_text().splitlines()})
+        (data / "test_users.tsv").write_text("".join(f"{u}\n" for u in ids[:60]) + "999999999\n")
     args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "7", "-rfreq", str(rfreq)] + flags
     if maxit is not None:
         args += ["-max-iterations", str(maxit)]
@@ -89,6 +98,15 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
         assert [x[0] for x in a] == [x[0] for x in b], f          # same report iterations (same stop)
         assert [x[2] for x in a] == [x[2] for x in b]
         assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    # ranking evaluation (compute_precision / compute_itemrank / gen_ranking_for_users)
+    assert (out / "precision.txt").read_text() == (ref / "precision.txt").read_text()
+    assert len((out / "precision.txt").read_text().splitlines()) >= 2
+    for f in ("ranking.tsv", "itemrank.tsv", "meanrank.txt"):
+        assert (out / f).exists() == (ref / f).exists(), f
+        if (ref / f).exists():
+            assert (out / f).read_text() == (ref / f).read_text(), f
+    if not hier or maxit == 100:
+        assert (out / "ranking.tsv").exists() and (out / "meanrank.txt").exists()
     la = [float(x) for x in (out / "logl.txt").read_text().split()]
     lb = [float(x) for x in (ref / "logl.txt").read_text().split()]
     assert len(la) == len(lb) and (len(la) > 0) == logl
@@ -107,7 +125,7 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
             assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf
             assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf   # in practice: print rounding only
     # files the reference's constructor creates even when they stay empty
-    for f in ("heldout.txt", "logl.txt", "precision.txt", "ndcg.txt", "rmse.txt", "infer.log", "param.txt"):
+    for f in ("heldout.txt", "logl.txt", "ndcg.txt", "rmse.txt", "infer.log", "param.txt"):
         assert (out / f).exists()
     keys = [l.split(":")[0] for l in (out / "param.txt").read_text().splitlines()]
     assert keys[:20] == ["n", "k", "t", "test_ratio", "validation_ratio", "seed", "a", "b", "c", "d",
