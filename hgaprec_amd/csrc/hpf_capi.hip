@@ -46,6 +46,7 @@ struct Side {
   bool have_E = false, have_L = false, have_prior = false;
   bool w_dirty = false;      // L was handed in by hpf_set_state: W must be derived from it
   bool l_stale = false;      // a sweep ran since L was last valid: rebuild L on export
+  bool es_stale = false;     // S holds raw phi sums and E predates the last sweep
 };
 
 }  // namespace
@@ -308,9 +309,25 @@ double host_digamma(double x)
   return acc + std::log(x) - 0.5 * xi - s;
 }
 
+// shape (prior added, in place) and E from the raw sums and the rate the last
+// sweep used; needed by every consumer outside the hot loop
+int refresh_es(hpf_handle *h, Side &s)
+{
+  if (!s.es_stale || !s.rows) { s.es_stale = false; return HPF_OK; }
+  const size_t ne = (size_t)s.rows * h->ld;
+  const uint32_t blocks = (uint32_t)std::min<size_t>((ne + 255) / 256, 8192);
+  hipLaunchKernelGGL(materialize_es_kernel, dim3(blocks), dim3(256), 0, h->stream, s.S, s.E, s.prior_used,
+                     s.colsum_used, s.rows, h->ld, h->K, s.bias_col, s.bias_rate_add, h->cfg.s_prior,
+                     h->cfg.r_prior, h->cfg.hier);
+  int rc = check_launch(h, "materialize_es_kernel");
+  if (!rc) s.es_stale = false;
+  return rc;
+}
+
 // rebuild Elog from shape and the rate the last sweep used (export only)
 int refresh_elog(hpf_handle *h, Side &s)
 {
+  { int rc0 = refresh_es(h, s); if (rc0) return rc0; }
   if (!s.l_stale || !s.rows) { s.l_stale = false; return HPF_OK; }
   const size_t ne = (size_t)s.rows * h->ld;
   const uint32_t blocks = (uint32_t)std::min<size_t>((ne + 255) / 256, 8192);
@@ -344,6 +361,7 @@ int prepare_derived(hpf_handle *h)
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
   {
     Side &s = h->it;
+    { int rc0 = refresh_es(h, s); if (rc0) return rc0; }
     const uint32_t nb = s.sweep_blocks;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, h->stream, s.E, s.rows,
                        h->ld, h->K, s.colsum_part);
@@ -381,8 +399,8 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   // remember what the rate was built from (export of *_rate.tsv)
   HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   SweepArgs a;
-  a.S = s.S; a.E = s.E; a.W = s.W;
-  s.l_stale = true;
+  a.S = s.S; a.W = s.W;
+  s.l_stale = true; s.es_stale = true;
   a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
   a.prior_elog = s.prior_elog; a.prior_elog_used = s.prior_elog_used;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
@@ -505,6 +523,11 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       int g2, r2;
       if (choose_cfg(h->ld, v, &g2, &r2)) { h->phiG = g2; h->phiR = r2; h->phiV = v; }
     }
+  }
+  if (const char *e = getenv("HPF_SWEEP_CFG")) {
+    int g = 0, r = 0;
+    if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= 8 && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
+        (uint32_t)(g * r) >= h->ld) { h->swG = g; h->swR = r; }
   }
   if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
@@ -681,6 +704,7 @@ int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t cou
     return HPF_OK;
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
+  if ((rc = refresh_es(h, *s))) return rc;     // the rest of S / E must be current before patching
   double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
   if ((rc = copy_in(h, dev, h->ld, (uint32_t)col0, host, rows, cols))) return rc;
   if (obj <= 1) {
@@ -768,7 +792,7 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
     return rc;
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
-  if (kind == 3) { int rc = refresh_elog(h, *s); if (rc) return rc; }
+  { int rc = kind == 3 ? refresh_elog(h, *s) : refresh_es(h, *s); if (rc) return rc; }
   const double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
   return copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
 }
@@ -800,6 +824,7 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     if (u[p] >= h->u.rows || i[p] >= h->it.rows) { h->err = "held-out index out of range"; return HPF_ERR_INVALID; }
   uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr;
   int rc = HPF_OK;
+  if ((rc = refresh_es(h, h->u)) || (rc = refresh_es(h, h->it))) return rc;
   std::vector<double> out(cnt);
   do {
     if ((rc = dalloc(h, &du, cnt)) || (rc = dalloc(h, &di, cnt)) || (rc = dalloc(h, &dy, cnt)) ||
@@ -901,6 +926,7 @@ int rank_prepare(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const uin
     for (uint64_t j = 0; j < nmask; ++j) if (mask_items[j] >= m) { h->err = "mask item out of range"; return HPF_ERR_INVALID; }
   }
   int rc;
+  if ((rc = refresh_es(h, h->u)) || (rc = refresh_es(h, h->it))) return rc;
   c.n_sel = n_sel;
   // rows of scores kept at once: <= 1 GiB, a multiple of 16
   uint64_t bmax = ((1ull << 30) / (8ull * std::max<uint32_t>(m, 1))) & ~15ull;

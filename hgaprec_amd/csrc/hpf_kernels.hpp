@@ -255,6 +255,17 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
 // ---------------------------------------------------------------------
 struct PsiParts { double xs, corr; };
 
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (5 instructions instead
+// of the ~15 of an IEEE-exact fp64 division); x is a positive normal number
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
 __device__ __forceinline__ PsiParts psi_parts(double x)
 {
   double p = 1.0, dp = 0.0;
@@ -262,7 +273,7 @@ __device__ __forceinline__ PsiParts psi_parts(double x)
 #pragma unroll
     for (int j = 0; j < 10; ++j) { dp = fma(dp, x, p); p *= x; x += 1.0; }
   }
-  const double xi = 1.0 / x, x2 = xi * xi;
+  const double xi = fast_rcp(x), x2 = xi * xi;
   double s = 1.0 / 12.0;
   s = fma(-x2, s, 691.0 / 32760.0);
   s = fma(-x2, s, 1.0 / 132.0);
@@ -272,7 +283,7 @@ __device__ __forceinline__ PsiParts psi_parts(double x)
   s = fma(-x2, s, 1.0 / 12.0);
   PsiParts r;
   r.xs = x;
-  r.corr = fma(x2, s, fma(0.5, xi, dp / p));
+  r.corr = fma(x2, s, fma(0.5, xi, dp * fast_rcp(p)));
   return r;
 }
 
@@ -286,7 +297,8 @@ __device__ __forceinline__ double digamma_pos(double x)
 // K2/K3 (+K4, K5, K7): row sweep.  One G-lane group per row, column
 // g + G*t in register slot t.  For every row (reference steps B/C, D, E/F of
 // hgaprec.cc:1370-1414; non-hier: 944-956, 1252-1268):
-//   shape = s_prior + S            (S = raw phi sums; written back as shape)
+//   shape = s_prior + S            (S = raw phi sums; left raw: shape and E are
+//                                   materialised on demand, materialize_es_kernel)
 //   rate  = prior_rate(row) + colsum_other[k]        k < K
 //           r_prior + n_other_total                   bias column
 //   E = shape/rate
@@ -296,8 +308,7 @@ __device__ __forceinline__ double digamma_pos(double x)
 //   block partial column sums of E  (-> colsum kernel, fixed order)
 // ---------------------------------------------------------------------
 struct SweepArgs {
-  double       *S;          // [rows x ld] in: raw sums, out: shape
-  double       *E;          // [rows x ld]
+  const double *S;          // [rows x ld] raw phi sums (read only)
   double       *W;          // [rows x ld]
   double       *prior_E;    // [rows] E[xi] / E[eta]: in old, out new (hier)
   double       *prior_used; // [rows] value of prior_E used for this rate
@@ -352,15 +363,13 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
           // GPBase::make_nonzero, gpbase.hh:27-44
           sh = (sh > 0.0) ? sh : 1e-30;
           rt = (rt > 0.0) ? rt : 1e-30;
-          e = sh / rt;
+          e = sh / rt;                              // exported: IEEE division like the reference
           const PsiParts ps = psi_parts(sh);
-          w[t] = ps.xs * exp(-ps.corr) / rt;        // exp(psi(shape) - log(rate))
+          w[t] = ps.xs * exp(-ps.corr) * fast_rcp(rt);   // exp(psi(shape) - log(rate))
           if (real) { rsum += e; csum[t] += e; }
         } else if (junk) {
           w[t] = 1.0;                               // Elog 0 in the other side's bias slot
         }
-        a.S[base + c] = sh;
-        a.E[base + c] = e;
         wmax = fmax(wmax, w[t]);
       }
     }
@@ -399,6 +408,32 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     double v = 0.0;
     if (c < (uint32_t)(G * R)) v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     a.colsum_part[(size_t)blockIdx.x * ld + c] = (c < K) ? v : 0.0;
+  }
+}
+
+// shape = s_prior + S_raw (in place) and E = shape / rate for export, held-out
+// likelihood, ranking and ELBO: the hot loop itself only needs W and the
+// column sums, so the sweep does not spend 16 B/element of writes on them.
+// Same expressions as the sweep => the same bits the sweep summed.
+__global__ void materialize_es_kernel(double *S, double *E, const double *prior_used,
+                                      const double *colsum_used, uint32_t rows, uint32_t ld, uint32_t K,
+                                      int32_t bias_col, double bias_rate_add, double s_prior,
+                                      double r_prior, uint32_t hier)
+{
+  const size_t n = (size_t)rows * ld;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t row = (uint32_t)(e / ld), c = (uint32_t)(e % ld);
+    double sh = 0.0, ev = 0.0;
+    if (c < K || (int32_t)c == bias_col) {
+      sh = s_prior + S[e];
+      double rt = (c < K) ? (hier ? prior_used[row] : r_prior) + colsum_used[c] : r_prior + bias_rate_add;
+      sh = (sh > 0.0) ? sh : 1e-30;
+      rt = (rt > 0.0) ? rt : 1e-30;
+      ev = sh / rt;
+    }
+    S[e] = sh;
+    E[e] = ev;
   }
 }
 

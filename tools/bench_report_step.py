@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Time the report-step operations (held-out LL, ELBO, ranking evaluation) at
+BASELINE config C2 on one GPU.  Prints one JSON line (milliseconds)."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    cfg = dict(synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C2"])
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate(cfg["n"], cfg["m"], cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                      seed=cfg["seed"], device=dev, binary=cfg["binary"])
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    D = Hpf(n, m, K, hier=True, bias=cfg["bias"], binary=cfg["binary"])
+    D.upload_csr(rowptr, col, val)
+    st = synth.initial_state(n, K, 1, dev); D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, 2, dev); D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    D.set_state("XI_E", synth.initial_state(n, K, 3, dev, prior_v=K)["E"])
+    D.set_state("XI_ELOG", synth.initial_state(n, K, 3, dev, prior_v=K)["Elog"])
+    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    D.set_state("ETA_ELOG", synth.initial_state(m, K, 4, dev, prior_v=K)["Elog"])
+    if cfg["bias"]:
+        for w, rows, v in (("UBIAS", n, m), ("IBIAS", m, n)):
+            s = synth.initial_state(rows, K, 5, dev, prior_v=v)
+            D.set_state(w + "_E", s["E"]); D.set_state(w + "_ELOG", s["Elog"])
+    D.iterate(3); D.synchronize()
+    hu, hi, hy = synth.heldout(n, m, int(rowptr[-1]) // 100, 7, dev, cfg["binary"])
+    out = {"config": sys.argv[1] if len(sys.argv) > 1 else "C2", "heldout_pairs": int(hu.size)}
+
+    def timed(name, fn, reps=3):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        out[name + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
+        return r
+
+    timed("heldout_ll", lambda: D.heldout_ll(hu, hi, hy))
+    out["elbo"] = timed("elbo", lambda: D.elbo())
+    rng = np.random.default_rng(0)
+    users = np.sort(rng.choice(n, 1000, replace=False)).astype(np.uint32)
+    mptr = np.zeros(1001, np.uint64)
+    items, sc = timed("rank_topn_1000users", lambda: D.rank_topn(users, 100, mptr, np.zeros(0, np.uint32)))
+    qs = np.arange(1000, dtype=np.uint32); qi = items[:, 5].copy()
+    rank, _ = timed("item_ranks_1000q", lambda: D.item_ranks(users, qs, qi, mptr, np.zeros(0, np.uint32)))
+    assert np.all(rank == 5)
+    t0 = time.perf_counter(); D.iterate(10); D.synchronize()
+    out["iteration_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

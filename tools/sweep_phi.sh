@@ -1,7 +1,3 @@
-for pb in 16384 65536 1048576; do
-  HPF_PHI_BLOCKS=$pb python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('blocks $pb', round(d['value']/1e9,3), d['kernels_ms'])"
+for cfg in "16,7" "32,4" "64,2" "16,8" "32,5"; do
+  HPF_SWEEP_CFG=$cfg python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('sweep $cfg', round(d['value']/1e9,3), d['kernels_ms'])"
 done
-for sm in 128 256 512; do
-  HPF_SEG_MAX=$sm python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('segmax $sm', round(d['value']/1e9,3), d['kernels_ms'])"
-done
-HPF_PHI_CFG=8,7,2 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('8,7,2', round(d['value']/1e9,3), d['kernels_ms'])"
