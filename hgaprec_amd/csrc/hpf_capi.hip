@@ -35,10 +35,15 @@ struct Side {
   double *rate_set = nullptr;     // rate handed in by hpf_set_state (export before iter 0)
   size_t  rate_set_count = 0;
   double *prior_shape_set = nullptr, *prior_elog_set = nullptr;  // xi/eta extras
-  // phi pass work lists
-  Seg *segs = nullptr; uint32_t nseg = 0;
-  LongRow *longrows = nullptr; uint32_t nlong = 0;
+  // phi pass work lists.  phases == 2: the nonzeros of every row are
+  // partitioned into those whose other-side row belongs to the "hot" set (the
+  // highest-degree rows whose W fits one XCD's 4 MiB L2) and the rest; phase 0
+  // walks the hot parts (gathers hit L2), phase 1 adds the cold parts.
+  uint32_t phases = 1;
+  Seg *segs[2] = {nullptr, nullptr}; uint32_t nseg[2] = {0, 0};
+  LongRow *longrows[2] = {nullptr, nullptr}; uint32_t nlong[2] = {0, 0};
   double *partial = nullptr; uint32_t npartial = 0;
+  double hot_share = 0.0; uint32_t hot_rows = 0;
   uint32_t *idx = nullptr; uint8_t *val = nullptr;
   int32_t bias_col = -1, junk_col = -1;
   double bias_rate_add = 0.0;
@@ -65,6 +70,10 @@ struct hpf_handle {
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
   uint32_t seg_max = 512;
+  bool hot_force = false;               // HPF_HOT_FORCE=1: split even when the estimate says no (tests)
+  uint64_t hot_bytes = 0;               // HPF_HOT_BYTES: size of the L2-resident hot set; 0 = single phase.
+                                        // Measured at C2 (3.5 MiB hot set): user pass 4.3 -> 5.7 ms -- the
+                                        // short hot/cold segments cost more than the L2 hits save; kept as a knob.
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][7] = {};
@@ -103,7 +112,8 @@ void free_side(Side &s, bool S_external)
   dfree(s.prior_elog); dfree(s.prior_elog_used);
   dfree(s.colsum_used); dfree(s.colsum_part);
   dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
-  dfree(s.segs); dfree(s.longrows); dfree(s.partial); dfree(s.idx); dfree(s.val);
+  dfree(s.segs[0]); dfree(s.segs[1]); dfree(s.longrows[0]); dfree(s.longrows[1]);
+  dfree(s.partial); dfree(s.idx); dfree(s.val);
   s = Side();
 }
 
@@ -128,8 +138,12 @@ bool choose_cfg(uint32_t ld, int V, int *G, int *R)
 template <int G, int R, int V>
 void launch_phi_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  if (side == 0) hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 0>), dim3(blocks), dim3(256), 0, st, a);
-  else           hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 1>), dim3(blocks), dim3(256), 0, st, a);
+  switch (side) {
+    case 0: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 0>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 3>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
 }
 template <int G, int V>
 bool launch_phi_r(int R, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
@@ -194,56 +208,109 @@ int check_launch(hpf_handle *h, const char *what)
 }
 
 // ---- work lists -----------------------------------------------------------
-void build_segments(const int64_t *ptr, uint32_t rows, uint32_t seg_max,
-                    std::vector<Seg> &segs, std::vector<LongRow> &longs,
-                    uint32_t *npartial)
+// segments of at most seg_max nonzeros for the row parts [start[r], start[r]+len[r]);
+// skip_empty: rows with len 0 get no segment (cold phase), else one empty segment
+void build_segments(const std::vector<int64_t> &start, const std::vector<uint32_t> &len,
+                    uint32_t seg_max, bool skip_empty, uint32_t *slot_io,
+                    std::vector<Seg> &segs, std::vector<LongRow> &longs)
 {
   segs.clear(); longs.clear();
-  uint32_t slot = 0;
+  uint32_t slot = *slot_io;
+  const uint32_t rows = (uint32_t)len.size();
   for (uint32_t r = 0; r < rows; ++r) {
-    const int64_t a = ptr[r], b = ptr[r + 1];
-    const uint64_t deg = (uint64_t)(b - a);
+    const uint64_t deg = len[r];
+    if (deg == 0 && skip_empty) continue;
     if (deg <= seg_max) {
-      Seg s; s.start = a; s.row = r; s.len = (uint32_t)deg; s.pslot = -1; s.pad = 0;
+      Seg s; s.start = start[r]; s.row = r; s.len = (uint32_t)deg; s.pslot = -1; s.pad = 0;
       segs.push_back(s);
     } else {
       const uint32_t ns = (uint32_t)((deg + seg_max - 1) / seg_max);
       LongRow lr; lr.row = r; lr.first_slot = slot; lr.nslots = ns; lr.pad = 0;
       longs.push_back(lr);
       for (uint32_t k = 0; k < ns; ++k) {
-        Seg s; s.start = a + (int64_t)k * seg_max; s.row = r;
+        Seg s; s.start = start[r] + (int64_t)k * seg_max; s.row = r;
         s.len = (uint32_t)std::min<uint64_t>(seg_max, deg - (uint64_t)k * seg_max);
         s.pslot = (int32_t)slot++; s.pad = 0;
         segs.push_back(s);
       }
     }
   }
-  *npartial = slot;
+  *slot_io = slot;
 }
 
+// deg_oth: degrees of the OTHER side's rows (rows_oth of them), used to pick the hot set
 int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
-                     const uint32_t *idx, const uint8_t *val, uint64_t nnz)
+                     const uint32_t *idx, const uint8_t *val, uint64_t nnz,
+                     const int64_t *ptr_oth, uint32_t rows_oth)
 {
-  std::vector<Seg> segs; std::vector<LongRow> longs; uint32_t np = 0;
-  build_segments(ptr, rows, h->seg_max, segs, longs, &np);
-  dfree(s.segs); dfree(s.longrows); dfree(s.partial); dfree(s.idx); dfree(s.val);
-  s.segs = nullptr; s.longrows = nullptr; s.partial = nullptr; s.idx = nullptr; s.val = nullptr;
-  s.nseg = (uint32_t)segs.size(); s.nlong = (uint32_t)longs.size(); s.npartial = np;
+  for (int p = 0; p < 2; ++p) { dfree(s.segs[p]); dfree(s.longrows[p]); s.segs[p] = nullptr; s.longrows[p] = nullptr; s.nseg[p] = s.nlong[p] = 0; }
+  dfree(s.partial); dfree(s.idx); dfree(s.val);
+  s.partial = nullptr; s.idx = nullptr; s.val = nullptr;
+  s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0;
+
+  // ---- hot set: the highest-degree other-side rows whose W rows fit in one L2
+  const uint64_t row_bytes = (uint64_t)h->ld * 8;
+  const uint32_t H = (uint32_t)std::min<uint64_t>(h->hot_bytes / row_bytes, rows_oth);
+  std::vector<uint8_t> hot;
+  if (H > 0 && H < rows_oth && nnz > 0) {
+    std::vector<uint32_t> order(rows_oth);
+    for (uint32_t r = 0; r < rows_oth; ++r) order[r] = r;
+    std::nth_element(order.begin(), order.begin() + H, order.end(), [&](uint32_t x, uint32_t y) {
+      const int64_t dx = ptr_oth[x + 1] - ptr_oth[x], dy = ptr_oth[y + 1] - ptr_oth[y];
+      return dx != dy ? dx > dy : x < y; });
+    uint64_t hot_nnz = 0;
+    for (uint32_t k = 0; k < H; ++k) hot_nnz += (uint64_t)(ptr_oth[order[k] + 1] - ptr_oth[order[k]]);
+    // worth it when the gathers that become L2 hits outweigh (2x) the extra
+    // read-modify-write of the owner rows in the second phase
+    const double gain = (double)hot_nnz * (double)row_bytes, cost = 2.0 * (double)rows * (double)row_bytes * 2.0;
+    if (gain > cost || h->hot_force) {
+      hot.assign(rows_oth, 0);
+      for (uint32_t k = 0; k < H; ++k) hot[order[k]] = 1;
+      s.phases = 2; s.hot_share = (double)hot_nnz / (double)nnz; s.hot_rows = H;
+    }
+  }
+
+  // ---- (re)order the nonzeros of each row: hot ones first, stable
+  std::vector<int64_t> start0(rows), start1(rows);
+  std::vector<uint32_t> len0(rows), len1(rows, 0);
+  std::vector<uint32_t> ridx; std::vector<uint8_t> rval;
+  const uint32_t *up_idx = idx; const uint8_t *up_val = val;
+  if (s.phases == 2) {
+    ridx.resize(nnz); if (val) rval.resize(nnz);
+    for (uint32_t r = 0; r < rows; ++r) {
+      const int64_t a = ptr[r], b = ptr[r + 1];
+      int64_t w = a;
+      for (int64_t j = a; j < b; ++j) if (hot[idx[j]]) { ridx[w] = idx[j]; if (val) rval[w] = val[j]; ++w; }
+      start0[r] = a; len0[r] = (uint32_t)(w - a); start1[r] = w; len1[r] = (uint32_t)(b - w);
+      for (int64_t j = a; j < b; ++j) if (!hot[idx[j]]) { ridx[w] = idx[j]; if (val) rval[w] = val[j]; ++w; }
+    }
+    up_idx = ridx.data(); up_val = val ? rval.data() : nullptr;
+  } else {
+    for (uint32_t r = 0; r < rows; ++r) { start0[r] = ptr[r]; len0[r] = (uint32_t)(ptr[r + 1] - ptr[r]); }
+  }
+
+  std::vector<Seg> segs[2]; std::vector<LongRow> longs[2]; uint32_t np = 0;
+  build_segments(start0, len0, h->seg_max, false, &np, segs[0], longs[0]);
+  if (s.phases == 2) build_segments(start1, len1, h->seg_max, true, &np, segs[1], longs[1]);
+  s.npartial = np;
   int rc;
-  if ((rc = dalloc(h, &s.segs, segs.size()))) return rc;
-  if ((rc = dalloc(h, &s.longrows, longs.size()))) return rc;
+  for (int p = 0; p < 2; ++p) {
+    s.nseg[p] = (uint32_t)segs[p].size(); s.nlong[p] = (uint32_t)longs[p].size();
+    if ((rc = dalloc(h, &s.segs[p], segs[p].size()))) return rc;
+    if ((rc = dalloc(h, &s.longrows[p], longs[p].size()))) return rc;
+    if (!segs[p].empty())
+      HIPCHK(h, hipMemcpyAsync(s.segs[p], segs[p].data(), segs[p].size() * sizeof(Seg), hipMemcpyHostToDevice, h->stream));
+    if (!longs[p].empty())
+      HIPCHK(h, hipMemcpyAsync(s.longrows[p], longs[p].data(), longs[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+  }
   if ((rc = dalloc(h, &s.partial, (size_t)np * h->ld))) return rc;
   if ((rc = dalloc(h, &s.idx, (size_t)nnz))) return rc;
-  if (!segs.empty())
-    HIPCHK(h, hipMemcpyAsync(s.segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, h->stream));
-  if (!longs.empty())
-    HIPCHK(h, hipMemcpyAsync(s.longrows, longs.data(), longs.size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
   if (nnz)
-    HIPCHK(h, hipMemcpyAsync(s.idx, idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(s.idx, up_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   if (val) {
     if ((rc = dalloc(h, &s.val, (size_t)nnz))) return rc;
     if (nnz)
-      HIPCHK(h, hipMemcpyAsync(s.val, val, nnz, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(s.val, up_val, nnz, hipMemcpyHostToDevice, h->stream));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));   // host vectors die here
   return HPF_OK;
@@ -376,20 +443,25 @@ int prepare_derived(hpf_handle *h)
 
 int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
-  PhiArgs a;
-  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
-  a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
-  if (own.nseg) {
-    const uint32_t blocks = std::min<uint32_t>((own.nseg + 3) / 4, h->phi_blocks);
-    if (!launch_phi(h->phiG, h->phiR, h->phiV, &own == &h->it ? 1 : 0, a, blocks, h->stream)) {
-      h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
+  const int side = &own == &h->it ? 1 : 0;
+  for (uint32_t ph = 0; ph < own.phases; ++ph) {
+    PhiArgs a;
+    a.segs = own.segs[ph]; a.nseg = own.nseg[ph]; a.idx = own.idx; a.val = own.val;
+    a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
+    a.accumulate = ph;
+    if (a.nseg) {
+      const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+      if (!launch_phi(h->phiG, h->phiR, h->phiV, side + 2 * (int)ph, a, blocks, h->stream)) {
+        h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
+      }
     }
-  }
-  HIPCHK(h, hipEventRecord(after_kernel, h->stream));
-  if (own.nlong) {
-    const uint32_t blocks = std::min<uint32_t>((own.nlong + 3) / 4, 16384);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       own.longrows, own.nlong, own.partial, own.S, h->ld);
+    // the event separates the (last) phi kernel from the combine that follows it
+    if (ph + 1 == own.phases) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
+    if (own.nlong[ph]) {
+      const uint32_t blocks = std::min<uint32_t>((own.nlong[ph] + 3) / 4, 16384);
+      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                         own.longrows[ph], own.nlong[ph], own.partial, own.S, h->ld, ph);
+    }
   }
   return check_launch(h, "phi pass");
 }
@@ -529,6 +601,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= 8 && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
         (uint32_t)(g * r) >= h->ld) { h->swG = g; h->swR = r; }
   }
+  if (const char *e = getenv("HPF_HOT_BYTES")) { long long v = atoll(e); if (v >= 0) h->hot_bytes = (uint64_t)v; }
+  if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
   if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
 
@@ -644,8 +718,8 @@ int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, co
       }
   }
   int rc;
-  if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz))) return rc;
-  if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz))) return rc;
+  if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz, colptr.data(), m))) return rc;
+  if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz, rowptr, n))) return rc;
   dfree(h->rowptr_dev); h->rowptr_dev = nullptr;
   if ((rc = dalloc(h, &h->rowptr_dev, (size_t)n + 1))) return rc;
   HIPCHK(h, hipMemcpyAsync(h->rowptr_dev, rowptr, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, h->stream));

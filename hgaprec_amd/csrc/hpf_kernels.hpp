@@ -94,10 +94,12 @@ struct PhiArgs {
   double         *S_own;    // [rows_own x ld]  raw sums (prior added by sweep)
   double         *partial;  // [npartial x ld]
   uint32_t        ld;       // row stride in doubles (even)
+  uint32_t        accumulate;  // 1: direct rows add to S_own (second phase of a hot/cold split)
 };
 
 // SIDE only names the instantiation (0 = user-major pass over CSR, 1 =
-// item-major pass over CSC) so that profilers report the two passes apart.
+// item-major pass over CSC; +2 = the "cold" phase of a hot/cold split) so
+// that profilers report the passes apart.
 template <int G, int R, int V, int SIDE>
 __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 {
@@ -211,8 +213,15 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
         if (G <= 4)  r += __shfl_xor(r, 4, 64);
         acc[t].x[v] = r;
       }
-      if (q == 0 && cok[t])
-        *reinterpret_cast<vecd<V> *>(dst + (size_t)(g + G * t) * V) = acc[t];
+      if (q == 0 && cok[t]) {
+        vecd<V> *pd = reinterpret_cast<vecd<V> *>(dst + (size_t)(g + G * t) * V);
+        if (a.accumulate && sg.pslot < 0) {      // S = (hot-phase sum) + (this phase's sum)
+          const vecd<V> old = *pd;
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[t].x[v] = old.x[v] + acc[t].x[v];
+        }
+        *pd = acc[t];
+      }
     }
   }
 }
@@ -221,7 +230,8 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 // One wave per long row, lane = column (+64, ...); the slot loop is unrolled
 // so that 8 independent loads are in flight per lane, the adds stay in order.
 __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
-                                                               const double *partial, double *S, uint32_t ld)
+                                                               const double *partial, double *S, uint32_t ld,
+                                                               uint32_t accumulate)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
         for (int j = 0; j < 8; ++j) s += v[j];
       }
       for (; q < lr.nslots; ++q) s += p[(size_t)q * ld];
-      S[(size_t)lr.row * ld + c] = s;
+      S[(size_t)lr.row * ld + c] = accumulate ? S[(size_t)lr.row * ld + c] + s : s;
     }
   }
 }

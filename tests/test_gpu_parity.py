@@ -214,3 +214,23 @@ def test_set_elog_again_mid_run(orc):
     D.iterate(2)
     for w in compare_states(True, True):
         assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_hot_cold_two_phase_pass(orc, monkeypatch, bias):
+    # force the L2 hot/cold split of the phi passes (normally only chosen at
+    # scale) with a 12-row hot set and short segments, so that hot parts, cold
+    # parts, empty cold parts and long rows in both phases all occur
+    K = 12
+    ld = (K + (2 if bias else 0) + 1) & ~1
+    monkeypatch.setenv("HPF_HOT_BYTES", str(12 * ld * 8))
+    monkeypatch.setenv("HPF_HOT_FORCE", "1")
+    monkeypatch.setenv("HPF_SEG_MAX", "32")
+    M, D = _run_pair(orc, 700, 300, K, 16000, True, bias, False, 4, seed=23,
+                     prob_kw=dict(heavy_user=True, heavy_item=True, singles=True))
+    for it in range(4):
+        M.iterate(1)
+        D.iterate(1)
+    for w in compare_states(True, bias):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+    assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
