@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n, m, nnz (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n", type=int, default=0, help="override users (experiments)")
+    ap.add_argument("--m", type=int, default=0, help="override items (experiments)")
+    ap.add_argument("--nnz", type=int, default=0, help="override nonzeros (experiments)")
+    ap.add_argument("--K", type=int, default=0, help="override factors (experiments)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
                          "single-GPU smoke test of the N>1 code path)")
@@ -106,6 +110,10 @@ def main():
     if args.scale != 1.0:
         for k in ("n", "m", "nnz"):
             cfg[k] = max(64, int(cfg[k] * args.scale))
+    for k in ("n", "m", "nnz", "K"):
+        if getattr(args, k):
+            cfg[k] = getattr(args, k)
+    custom = args.scale != 1.0 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
     n_loc, m, K = cfg["n"], cfg["m"], cfg["K"]
 
     # ---- synthetic shard (generated on the GPU, handed over as host CSR)
@@ -200,7 +208,7 @@ def main():
         achieved = ab[kern] / (kms * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
+        if tf.exists() and not custom:
             try:
                 traffic = json.loads(tf.read_text()).get(f"{args.config}:{kern}")
             except Exception:

@@ -34,6 +34,7 @@ EXPORTS = [
     "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
+    "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
     "hpf_algorithmic_bytes",
 ]
 
@@ -99,6 +100,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_scores.argtypes = [vp, u32p, C.c_uint32, dp]
     lib.hpf_rank_topn.argtypes = [vp, u32p, C.c_uint32, u64p, u32p, C.c_uint32, u32p, dp]
     lib.hpf_item_ranks.argtypes = [vp, u32p, C.c_uint32, u64p, u32p, u32p, u32p, C.c_uint32, u32p, dp]
+    lib.hpf_comm_unique_id.argtypes = [vp]
+    lib.hpf_comm_init.argtypes = [vp, vp]
+    lib.hpf_allreduce_exchange.argtypes = [vp]
+    lib.hpf_exchange_read.argtypes = [vp, dp, C.c_size_t]
+    lib.hpf_exchange_write.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_synchronize.argtypes = [vp]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
@@ -215,6 +221,30 @@ class Hpf:
 
     def bind_exchange_buffer(self, dev_ptr: int, count: int):
         self._check(self.lib.hpf_bind_exchange_buffer(self._h, C.c_void_p(dev_ptr), count))
+
+    def exchange_read(self) -> np.ndarray:
+        out = np.empty(self.exchange_count(), dtype=np.float64)
+        self._check(self.lib.hpf_exchange_read(self._h, _ptr(out, C.c_double), out.size))
+        return out
+
+    def exchange_write(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        self._check(self.lib.hpf_exchange_write(self._h, _ptr(a, C.c_double), a.size))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load_library().hpf_comm_unique_id(buf)
+        if rc != HPF_OK:
+            raise HpfError(f"hpf_comm_unique_id failed ({rc}): is librccl.so available?")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.hpf_comm_init(self._h, buf))
+
+    def allreduce_exchange(self):
+        self._check(self.lib.hpf_allreduce_exchange(self._h))
 
     def exchange_count(self):
         return self.exchange_buffer()[1]

@@ -66,7 +66,9 @@ int Env::parse(int argc, char **argv, bool echo, std::string *bad)
     else if (!strcmp(s, "-novb")) { vb = false; }
     else if (!strcmp(s, "-wals_l") || !strcmp(s, "-wals_C")) { next(); }
     else if (!strcmp(s, "-rating-threshold")) { rating_threshold = (uint32_t)atoi(next()); }
-    else if (!strcmp(s, "-device")) { device = atoi(next()); }      // extension: HIP device ordinal
+    else if (!strcmp(s, "-device")) { device = atoi(next()); device_set = true; }   // extension: HIP device ordinal
+    else if (!strcmp(s, "-ngpus")) { ngpus = atoi(next()); if (ngpus < 1) ngpus = 1; } // extension: one process per GPU
+    else if (!strcmp(s, "-comm")) { comm_mode = next(); }            // extension: rccl | host
     else if (i > 0) {
       if (bad) *bad = s;
       return 1;
@@ -442,61 +444,78 @@ double digamma(double x)
 namespace {
 const double SPRIOR = 0.3, RPRIOR = 0.3;       // hgaprec.cc:13-20
 
-// GPMatrix::initialize (gpbase.hh:292-308): n*k shape draws, then k rate draws
-void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate,
+// Each helper draws for ALL `rows` rows (the stream position is what the
+// reference's is) and stores only rows [lo, hi).
+
+// GPMatrix::initialize (gpbase.hh:292-308): rows*k shape draws, then k rate draws
+void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate, uint32_t lo, uint32_t hi,
                    std::vector<double> &shape, std::vector<double> &rate)
 {
-  shape.resize((size_t)rows * k);
-  for (size_t e = 0; e < shape.size(); ++e) shape[e] = SPRIOR + 0.01 * r.uniform();
+  shape.resize((size_t)(hi - lo) * k);
+  for (uint32_t i = 0; i < rows; ++i)
+    for (uint32_t j = 0; j < k; ++j) {
+      const double v = SPRIOR + 0.01 * r.uniform();
+      if (i >= lo && i < hi) shape[(size_t)(i - lo) * k + j] = v;
+    }
   std::vector<double> b0(k);
   for (uint32_t j = 0; j < k; ++j) b0[j] = RPRIOR + 0.1 * r.uniform();
   if (global_rate) rate = b0;                   // GPMatrixGR::initialize gpbase.hh:651-663
   else {
-    rate.resize((size_t)rows * k);
-    for (uint32_t i = 0; i < rows; ++i) for (uint32_t j = 0; j < k; ++j) rate[(size_t)i * k + j] = b0[j];
+    rate.resize((size_t)(hi - lo) * k);
+    for (uint32_t i = 0; i < hi - lo; ++i) for (uint32_t j = 0; j < k; ++j) rate[(size_t)i * k + j] = b0[j];
   }
 }
 // initialize_exp (gpbase.hh:324-340 / 700-715): fresh rate draw per element
-void gp_initialize_exp(Mt19937 &r, const std::vector<double> &shape,
-                       std::vector<double> &E, std::vector<double> &Elog)
+void gp_initialize_exp(Mt19937 &r, uint32_t rows, uint32_t k, uint32_t lo, uint32_t hi,
+                       const std::vector<double> &shape, std::vector<double> &E, std::vector<double> &Elog)
 {
   E.resize(shape.size()); Elog.resize(shape.size());
-  for (size_t e = 0; e < shape.size(); ++e) {
-    const double b = RPRIOR + 0.1 * r.uniform();
-    E[e] = shape[e] / b;
-    Elog[e] = digamma(shape[e]) - std::log(b);
-  }
+  for (uint32_t i = 0; i < rows; ++i)
+    for (uint32_t j = 0; j < k; ++j) {
+      const double b = RPRIOR + 0.1 * r.uniform();
+      if (i >= lo && i < hi) {
+        const size_t e = (size_t)(i - lo) * k + j;
+        E[e] = shape[e] / b;
+        Elog[e] = digamma(shape[e]) - std::log(b);
+      }
+    }
 }
 // initialize2(v) + compute_expectations (gpbase.hh:310-322,939-949; 248-262,912-925)
-void gp_initialize2(Mt19937 &r, uint32_t rows, double v, std::vector<double> &shape,
+void gp_initialize2(Mt19937 &r, uint32_t rows, double v, uint32_t lo, uint32_t hi, std::vector<double> &shape,
                     std::vector<double> &rate, std::vector<double> &E, std::vector<double> &Elog)
 {
-  shape.resize(rows); rate.resize(rows); E.resize(rows); Elog.resize(rows);
-  for (uint32_t i = 0; i < rows; ++i) { shape[i] = SPRIOR + 0.01 * r.uniform(); rate[i] = RPRIOR + v; }
-  for (uint32_t i = 0; i < rows; ++i) { E[i] = shape[i] / rate[i]; Elog[i] = digamma(shape[i]) - std::log(rate[i]); }
+  const uint32_t keep = hi - lo;
+  shape.resize(keep); rate.resize(keep); E.resize(keep); Elog.resize(keep);
+  for (uint32_t i = 0; i < rows; ++i) {
+    const double s = SPRIOR + 0.01 * r.uniform();
+    if (i >= lo && i < hi) { shape[i - lo] = s; rate[i - lo] = RPRIOR + v; }
+  }
+  for (uint32_t i = 0; i < keep; ++i) { E[i] = shape[i] / rate[i]; Elog[i] = digamma(shape[i]) - std::log(rate[i]); }
 }
 }  // namespace
 
 void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hier,
-                      bool bias, GammaState *s)
+                      bool bias, GammaState *s, uint32_t lo, uint32_t hi)
 {
-  s->n = n; s->m = m; s->k = k; s->hier = hier; s->bias = bias;
+  if (hi > n) hi = n;
+  if (lo > hi) lo = hi;
+  s->n = hi - lo; s->m = m; s->k = k; s->hier = hier; s->bias = bias;
   if (!hier) {                                   // hgaprec.cc:156-161
-    gp_initialize(rng, m, k, true, s->beta_shape, s->beta_rate);
-    gp_initialize(rng, n, k, true, s->theta_shape, s->theta_rate);
-    gp_initialize_exp(rng, s->beta_shape, s->beta_E, s->beta_Elog);
-    gp_initialize_exp(rng, s->theta_shape, s->theta_E, s->theta_Elog);
+    gp_initialize(rng, m, k, true, 0, m, s->beta_shape, s->beta_rate);
+    gp_initialize(rng, n, k, true, lo, hi, s->theta_shape, s->theta_rate);
+    gp_initialize_exp(rng, m, k, 0, m, s->beta_shape, s->beta_E, s->beta_Elog);
+    gp_initialize_exp(rng, n, k, lo, hi, s->theta_shape, s->theta_E, s->theta_Elog);
   } else {                                       // hgaprec.cc:173-193
-    gp_initialize2(rng, n, (double)k, s->xi_shape, s->xi_rate, s->xi_E, s->xi_Elog);
-    gp_initialize2(rng, m, (double)k, s->eta_shape, s->eta_rate, s->eta_E, s->eta_Elog);
-    gp_initialize(rng, m, k, false, s->beta_shape, s->beta_rate);
-    gp_initialize_exp(rng, s->beta_shape, s->beta_E, s->beta_Elog);
-    gp_initialize(rng, n, k, false, s->theta_shape, s->theta_rate);
-    gp_initialize_exp(rng, s->theta_shape, s->theta_E, s->theta_Elog);
+    gp_initialize2(rng, n, (double)k, lo, hi, s->xi_shape, s->xi_rate, s->xi_E, s->xi_Elog);
+    gp_initialize2(rng, m, (double)k, 0, m, s->eta_shape, s->eta_rate, s->eta_E, s->eta_Elog);
+    gp_initialize(rng, m, k, false, 0, m, s->beta_shape, s->beta_rate);
+    gp_initialize_exp(rng, m, k, 0, m, s->beta_shape, s->beta_E, s->beta_Elog);
+    gp_initialize(rng, n, k, false, lo, hi, s->theta_shape, s->theta_rate);
+    gp_initialize_exp(rng, n, k, lo, hi, s->theta_shape, s->theta_E, s->theta_Elog);
   }
   if (bias) {                                    // hgaprec.cc:197-203
-    gp_initialize2(rng, n, (double)m, s->ubias_shape, s->ubias_rate, s->ubias_E, s->ubias_Elog);
-    gp_initialize2(rng, m, (double)n, s->ibias_shape, s->ibias_rate, s->ibias_E, s->ibias_Elog);
+    gp_initialize2(rng, n, (double)m, lo, hi, s->ubias_shape, s->ubias_rate, s->ubias_E, s->ubias_Elog);
+    gp_initialize2(rng, m, (double)n, 0, m, s->ibias_shape, s->ibias_rate, s->ibias_E, s->ibias_Elog);
   }
 }
 
@@ -504,15 +523,16 @@ void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hie
 // writers
 // ======================================================================
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
-                const uint32_t *seq2id, uint32_t nids)
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0)
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
   std::vector<char> big(1 << 20);
   setvbuf(tf, big.data(), _IOFBF, big.size());
   for (uint32_t i = 0; i < rows; ++i) {
-    const uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
-    fprintf(tf, "%d\t", i);
+    const uint32_t seq = i + row0;
+    const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
+    fprintf(tf, "%d\t", seq);
     fprintf(tf, "%d\t", id);
     for (uint32_t k = 0; k < cols; ++k)
       fprintf(tf, (k == cols - 1) ? "%.8f\n" : "%.8f\t", a[(size_t)i * cols + k]);
@@ -522,13 +542,14 @@ int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_
 }
 
 int save_vector(const std::string &path, const double *a, uint32_t rows,
-                const uint32_t *seq2id, uint32_t nids)
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0)
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
   for (uint32_t i = 0; i < rows; ++i) {
-    const uint32_t id = (seq2id && i < nids) ? seq2id[i] : i;
-    fprintf(tf, "%d\t", i);
+    const uint32_t seq = i + row0;
+    const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
+    fprintf(tf, "%d\t", seq);
     fprintf(tf, "%d\t", id);
     fprintf(tf, "%.8f\n", a[i]);
   }
@@ -553,4 +574,124 @@ bool StopRule::update(uint32_t iter, double a, int *why)
   return stop;
 }
 
+
+// ======================================================================
+// Comm: TCP star through rank 0
+// ======================================================================
+}  // namespace hgaprec
+
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+
+namespace hgaprec {
+
+namespace {
+int send_all(int fd, const void *p, size_t n)
+{
+  const char *c = (const char *)p;
+  while (n) { ssize_t w = ::send(fd, c, n, MSG_NOSIGNAL); if (w <= 0) { if (errno == EINTR) continue; return -1; } c += w; n -= (size_t)w; }
+  return 0;
+}
+int recv_all(int fd, void *p, size_t n)
+{
+  char *c = (char *)p;
+  while (n) { ssize_t r = ::recv(fd, c, n, 0); if (r <= 0) { if (r < 0 && errno == EINTR) continue; return -1; } c += r; n -= (size_t)r; }
+  return 0;
+}
+}  // namespace
+
+int Comm::init(int rank_, int world_, const std::string &addr, int port)
+{
+  rank = rank_; world = world_;
+  if (world <= 1) return 0;
+  if (rank == 0) {
+    int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) return -1;
+    int one = 1; setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (::bind(ls, (sockaddr *)&sa, sizeof sa) < 0 || ::listen(ls, world) < 0) { ::close(ls); return -1; }
+    fds.assign(world, -1);
+    for (int k = 1; k < world; ++k) {
+      int fd = ::accept(ls, nullptr, nullptr);
+      if (fd < 0) { ::close(ls); return -1; }
+      setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+      int32_t r = -1;
+      if (recv_all(fd, &r, 4) || r <= 0 || r >= world || fds[r] >= 0) { ::close(fd); ::close(ls); return -1; }
+      fds[r] = fd;
+    }
+    ::close(ls);
+  } else {
+    sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) return -1;
+    int fd = -1;
+    for (int tries = 0; tries < 600; ++tries) {            // rank 0 may not listen yet
+      fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (fd < 0) return -1;
+      if (::connect(fd, (sockaddr *)&sa, sizeof sa) == 0) break;
+      ::close(fd); fd = -1;
+      usleep(100000);
+    }
+    if (fd < 0) return -1;
+    int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    int32_t r = rank;
+    if (send_all(fd, &r, 4)) { ::close(fd); return -1; }
+    fds.assign(1, fd);
+  }
+  return 0;
+}
+
+void Comm::close_all()
+{
+  for (int fd : fds) if (fd >= 0) ::close(fd);
+  fds.clear();
+}
+
+int Comm::reduce_impl(double *v, size_t n, bool is_max)
+{
+  if (world <= 1 || n == 0) return 0;
+  if (rank == 0) {
+    std::vector<double> tmp(n);
+    for (int k = 1; k < world; ++k) {                      // rank order: deterministic sums
+      if (recv_all(fds[k], tmp.data(), n * 8)) return -1;
+      if (is_max) { for (size_t i = 0; i < n; ++i) v[i] = std::max(v[i], tmp[i]); }
+      else { for (size_t i = 0; i < n; ++i) v[i] += tmp[i]; }
+    }
+    for (int k = 1; k < world; ++k) if (send_all(fds[k], v, n * 8)) return -1;
+  } else {
+    if (send_all(fds[0], v, n * 8) || recv_all(fds[0], v, n * 8)) return -1;
+  }
+  return 0;
+}
+int Comm::allreduce_sum(double *v, size_t n) { return reduce_impl(v, n, false); }
+int Comm::allreduce_max(double *v, size_t n) { return reduce_impl(v, n, true); }
+
+int Comm::bcast(void *p, size_t bytes)
+{
+  if (world <= 1 || bytes == 0) return 0;
+  if (rank == 0) { for (int k = 1; k < world; ++k) if (send_all(fds[k], p, bytes)) return -1; return 0; }
+  return recv_all(fds[0], p, bytes);
+}
+
+int Comm::barrier() { double z = 0.0; return allreduce_sum(&z, 1); }
+
+std::vector<std::pair<uint32_t, uint32_t>> partition_users(const std::vector<int64_t> &rowptr, int world)
+{
+  const uint32_t n = (uint32_t)rowptr.size() - 1;
+  const int64_t nnz = rowptr[n];
+  std::vector<uint32_t> cuts(1, 0);
+  for (int r = 1; r < world; ++r) {
+    const int64_t target = nnz * r / world;
+    uint32_t c = (uint32_t)(std::lower_bound(rowptr.begin(), rowptr.end(), target) - rowptr.begin());
+    c = std::max<uint32_t>(c, cuts.back() + 1);            // at least one user per rank ...
+    const uint32_t cap = n > (uint32_t)(world - r) ? n - (uint32_t)(world - r) : 0;
+    c = std::min<uint32_t>(c, cap);                        // ... and one left for each later rank
+    cuts.push_back(std::max<uint32_t>(c, cuts.back()));
+  }
+  cuts.push_back(n);
+  std::vector<std::pair<uint32_t, uint32_t>> out;
+  for (int r = 0; r < world; ++r) out.emplace_back(cuts[r], cuts[r + 1]);
+  return out;
+}
 }  // namespace hgaprec

@@ -26,8 +26,11 @@ struct Env {
   // flags that are parsed (they are part of the CLI) but select code that is
   // outside the hot path; `unsupported` names the first one seen
   std::string unsupported;
-  // not part of the reference CLI: device ordinal for the HIP side
-  int device = 0;
+  // not part of the reference CLI: device ordinal for the HIP side, number of
+  // GPUs (one process each) and how the per-iteration all-reduce is carried
+  int device = 0; bool device_set = false;
+  int ngpus = 1;
+  std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)
 
   std::string prefix;          // output directory (Env::prefix)
   FILE *plogf = nullptr;       // param.txt
@@ -122,19 +125,25 @@ struct GammaState {
   std::vector<double> ubias_shape, ubias_rate, ubias_E, ubias_Elog;
   std::vector<double> ibias_shape, ibias_rate, ibias_E, ibias_Elog;
 };
-// hgaprec.cc:153-204 with the RNG already seeded as hgaprec.cc:34-38
+// hgaprec.cc:153-204 with the RNG already seeded as hgaprec.cc:34-38.
+// [user_lo, user_hi): keep only that range of the user-side arrays (a rank's
+// shard); the whole MT19937 stream is still consumed in the reference's
+// order, so every rank ends with the same generator state and the same
+// item-side arrays.  out->n is the number of users kept.
 void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hier,
-                      bool bias, GammaState *out);
+                      bool bias, GammaState *out, uint32_t user_lo = 0,
+                      uint32_t user_hi = 0xffffffffu);
 // the seed rule of hgaprec.cc:34-38 (+ GSL_RNG_SEED like gsl_rng_env_setup)
 Mt19937 make_rng(double env_seed);
 
 // ------------------------------------------------------------ writers -----
 // D2Array<double>::save / D1Array<double>::save: "seq\tid\tv...\n", %.8f;
 // id = seq2id[row] when row < nids else the row index itself
+// row0: sequence number of the first row (a rank writing its shard of a matrix)
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
-                const uint32_t *seq2id, uint32_t nids);
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0);
 int save_vector(const std::string &path, const double *a, uint32_t rows,
-                const uint32_t *seq2id, uint32_t nids);
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0);
 
 // ------------------------------------------- held-out series / stopping ---
 // HGAPRec::compute_likelihood bookkeeping (hgaprec.cc:1466-1500)
@@ -143,5 +152,27 @@ struct StopRule {
   // returns true when the run must stop; *why as written to max.txt
   bool update(uint32_t iter, double a, int *why);
 };
+
+// ------------------------------------------------------------- Comm --------
+// Host-side collectives of a multi-process run (one process per GPU): a TCP
+// star through rank 0 on MASTER_ADDR:MASTER_PORT.  Used for the bootstrap (the
+// RCCL unique id), the few scalars per report step, and -- with `-comm host`
+// -- a host-staged stand-in for the device all-reduce (tests on one GPU).
+// Sums are formed on rank 0 in rank order, so every rank sees the same bits.
+struct Comm {
+  int rank = 0, world = 1;
+  std::vector<int> fds;       // rank 0: one socket per peer (index = peer rank); others: fds[0]
+  int init(int rank_, int world_, const std::string &addr, int port);   // 0 / -1
+  void close_all();
+  int allreduce_sum(double *v, size_t n);
+  int allreduce_max(double *v, size_t n);
+  int bcast(void *p, size_t bytes);          // from rank 0
+  int barrier();
+ private:
+  int reduce_impl(double *v, size_t n, bool is_max);
+};
+
+// contiguous user ranges balanced on the nnz prefix sum
+std::vector<std::pair<uint32_t, uint32_t>> partition_users(const std::vector<int64_t> &rowptr, int world);
 
 }  // namespace hgaprec

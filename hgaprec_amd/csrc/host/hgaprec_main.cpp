@@ -2,9 +2,16 @@
 //
 // Same flags, input files and output files as the reference's src/main.cc +
 // HGAPRec::vb_hier / vb / vb_bias (hgaprec.cc:1321-1436, 919-980, 1219-1319);
-// the CAVI sweeps run on the GPU through include/hpf.h.  What stays on the
-// host is what the reference also does outside the hot loop: parsing, TSV
-// I/O, the MT19937 start state, the held-out series and its stop rule.
+// the CAVI sweeps, the held-out likelihood, the ELBO and the ranking
+// evaluation run on the GPU through include/hpf.h.  What stays on the host is
+// what the reference also does outside the hot loop: parsing, TSV I/O, the
+// MT19937 start state, the report series and their stop rule.
+//
+// Extension: `-ngpus N` shards the users over N GPUs of the node, one process
+// per GPU (the parent re-executes itself N times); per iteration the item-side
+// sums go through one RCCL all-reduce (`-comm rccl`, default) or a host-staged
+// stand-in (`-comm host`, for tests on a single GPU).  The output files are
+// the same as in a single-GPU run.
 //
 // Out of scope: competitor bridges, MLE/Canny ablations,
 // -gen-ranking/-msr/-rmse report modes; their flags are recognised and refused.
@@ -13,10 +20,13 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cerrno>
 #include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <vector>
 
 using namespace hgaprec;
@@ -27,37 +37,53 @@ static void term_handler(int) { g_save_state_now = 1; }   // main.cc:19-30
 namespace {
 
 struct Driver {
-  Env &env; Ratings &rt; hpf_handle *h = nullptr;
-  uint32_t n, m, k, iter = 0;
+  Env &env; Ratings &rt; Comm &comm; hpf_handle *h = nullptr;
+  uint32_t n, m, k, iter = 0;          // n: ALL users; lo..hi: this rank's range
+  uint32_t lo = 0, hi = 0;
+  bool use_rccl = false;
   time_t start;
   FILE *vf = nullptr, *tf = nullptr, *af = nullptr, *pf = nullptr;
   StopRule stop;
   Mt19937 rng;                         // gsl_rng *_r: keeps running after initialize()
-  std::vector<uint32_t> sampled;       // _sampled_users (std::map keys: sorted, unique)
+  std::vector<uint32_t> sampled;       // _sampled_users (std::map keys: sorted, unique), GLOBAL seq ids
   std::vector<uint32_t> item_deg;      // _movies[m]->size()
+  HeldOut lvalid, ltest;               // this rank's held-out pairs, LOCAL user indices
+  std::vector<double> xbuf;            // host staging of the exchange buffer (-comm host)
 
-  Driver(Env &e, Ratings &r) : env(e), rt(r), n(r.n), m(r.m), k(e.k), start(time(0)) {}
+  Driver(Env &e, Ratings &r, Comm &c) : env(e), rt(r), comm(c), n(r.n), m(r.m), k(e.k), start(time(0)) {}
 
+  bool root() const { return comm.rank == 0; }
   uint32_t duration() const { return (uint32_t)(time(0) - start); }      // hgaprec.hh:164-169
 
   void die(const char *what, int rc) {
-    fprintf(stderr, "error: %s: %s (%s)\n", what, hpf_strerror(rc), h ? hpf_last_error(h) : "");
+    fprintf(stderr, "error: [rank %d] %s: %s (%s)\n", comm.rank, what, hpf_strerror(rc), h ? hpf_last_error(h) : "");
     exit(-1);
+  }
+  void comm_check(int rc, const char *what) {
+    if (rc) { fprintf(stderr, "error: [rank %d] %s: peer lost\n", comm.rank, what); exit(-1); }
+  }
+
+  static void slice(const HeldOut &src, uint32_t a, uint32_t b, HeldOut *dst) {
+    dst->u.clear(); dst->i.clear(); dst->y.clear();
+    for (size_t p = 0; p < src.u.size(); ++p)
+      if (src.u[p] >= a && src.u[p] < b) { dst->u.push_back(src.u[p] - a); dst->i.push_back(src.i[p]); dst->y.push_back(src.y[p]); }
   }
 
   // HGAPRec::HGAPRec (hgaprec.cc:8-98): output files, held-out sets, prior log
   void construct() {
-    env.plog("infer n:", n);
-    const char *names[] = {"/heldout.txt", "/validation.txt", "/test.txt", "/logl.txt",
-                           "/precision.txt", "/ndcg.txt", "/rmse.txt"};
-    for (const char *nm : names) {
-      FILE *f = fopen(env.file_str(nm).c_str(), "w");
-      if (!f) { printf("cannot open heldout file:%s\n", strerror(errno)); exit(-1); }
-      if (!strcmp(nm, "/validation.txt")) vf = f;
-      else if (!strcmp(nm, "/test.txt")) tf = f;
-      else if (!strcmp(nm, "/logl.txt")) af = f;
-      else if (!strcmp(nm, "/precision.txt")) pf = f;
-      else fclose(f);
+    if (root()) {
+      env.plog("infer n:", n);
+      const char *names[] = {"/heldout.txt", "/validation.txt", "/test.txt", "/logl.txt",
+                             "/precision.txt", "/ndcg.txt", "/rmse.txt"};
+      for (const char *nm : names) {
+        FILE *f = fopen(env.file_str(nm).c_str(), "w");
+        if (!f) { printf("cannot open heldout file:%s\n", strerror(errno)); exit(-1); }
+        if (!strcmp(nm, "/validation.txt")) vf = f;
+        else if (!strcmp(nm, "/test.txt")) tf = f;
+        else if (!strcmp(nm, "/logl.txt")) af = f;
+        else if (!strcmp(nm, "/precision.txt")) pf = f;
+        else fclose(f);
+      }
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
     int rc = rt.read_heldout(env.datfname + "/validation.tsv", &rt.validation);
@@ -66,37 +92,56 @@ struct Driver {
     rc = rt.read_heldout(env.datfname + "/test.tsv", &rt.test);
     assert(rc != -1);
     if (rc) exit(-1);
-    printf("+ loaded validation and test sets from %s\n", env.datfname.c_str());
-    fflush(stdout);
-    env.plog("test ratings", (uint64_t)rt.test.u.size());
-    env.plog("validation ratings", (uint64_t)rt.validation.u.size());
-    if (!env.hier) {
-      env.plog("theta shape:", 0.3); env.plog("theta rate:", 0.3);
-      env.plog("beta shape:", 0.3); env.plog("beta rate:", 0.3);
-    } else {
-      env.plog("htheta shape:", 0.3); env.plog("htheta rate:", 0.3);
-      env.plog("hbeta shape:", 0.3); env.plog("hbeta rate:", 0.3);
-      env.plog("thetarate shape:", 0.3); env.plog("thetarate rate:", 0.3);
-      env.plog("betarate shape:", 0.3); env.plog("betarate rate:", 0.3);
+    if (root()) {
+      printf("+ loaded validation and test sets from %s\n", env.datfname.c_str());
+      fflush(stdout);
+      env.plog("test ratings", (uint64_t)rt.test.u.size());
+      env.plog("validation ratings", (uint64_t)rt.validation.u.size());
+      if (!env.hier) {
+        env.plog("theta shape:", 0.3); env.plog("theta rate:", 0.3);
+        env.plog("beta shape:", 0.3); env.plog("beta rate:", 0.3);
+      } else {
+        env.plog("htheta shape:", 0.3); env.plog("htheta rate:", 0.3);
+        env.plog("hbeta shape:", 0.3); env.plog("hbeta rate:", 0.3);
+        env.plog("thetarate shape:", 0.3); env.plog("thetarate rate:", 0.3);
+        env.plog("betarate shape:", 0.3); env.plog("betarate rate:", 0.3);
+      }
     }
+
+    // this rank's contiguous user range, balanced on the nnz prefix sum
+    const auto parts = partition_users(rt.rowptr, comm.world);
+    lo = parts[comm.rank].first; hi = parts[comm.rank].second;
+    slice(rt.validation, lo, hi, &lvalid);
+    slice(rt.test, lo, hi, &ltest);
 
     hpf_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
-    cfg.n_users = n; cfg.n_items = m; cfg.K = k;
+    cfg.n_users = hi - lo; cfg.n_items = m; cfg.K = k;
     cfg.hier = env.hier; cfg.bias = env.bias; cfg.binary = env.binary_data;
-    cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = 1; cfg.rank = 0;
+    cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = (uint32_t)comm.world; cfg.rank = (uint32_t)comm.rank;
     cfg.s_prior = 0.3; cfg.r_prior = 0.3;
     rc = hpf_create(&cfg, &h);
     if (rc) die("hpf_create (is an MI355X visible? there is no CPU fallback)", rc);
-    rc = hpf_upload_csr(h, rt.rowptr.data(), rt.col.data(), env.binary_data ? nullptr : rt.val.data());
+    std::vector<int64_t> rp(rt.rowptr.begin() + lo, rt.rowptr.begin() + hi + 1);
+    const int64_t base = rp[0];
+    for (auto &v : rp) v -= base;
+    rc = hpf_upload_csr(h, rp.data(), rt.col.data() + base, env.binary_data ? nullptr : rt.val.data() + base);
     if (rc) die("hpf_upload_csr", rc);
+
+    if (comm.world > 1 && use_rccl) {                      // bootstrap the RCCL communicator
+      char id[HPF_COMM_ID_BYTES]; memset(id, 0, sizeof id);
+      if (root() && (rc = hpf_comm_unique_id(id))) die("hpf_comm_unique_id (librccl.so missing?)", rc);
+      comm_check(comm.bcast(id, sizeof id), "bcast of the RCCL id");
+      if ((rc = hpf_comm_init(h, id))) die("hpf_comm_init", rc);
+    }
   }
 
-  // HGAPRec::initialize (hgaprec.cc:153-204): MT19937 on the host, state to the device
+  // HGAPRec::initialize (hgaprec.cc:153-204): MT19937 on the host, state to the device.
+  // Every rank consumes the whole stream (same generator state everywhere afterwards).
   void initialize() {
     rng = make_rng(env.seed);
     GammaState s;
-    initialize_state(rng, n, m, k, env.hier, env.bias, &s);
+    initialize_state(rng, n, m, k, env.hier, env.bias, &s, lo, hi);
     auto put = [&](hpf_state w, const std::vector<double> &v) {
       int rc = hpf_set_state(h, w, v.data(), v.size());
       if (rc) die("hpf_set_state", rc);
@@ -115,53 +160,104 @@ struct Driver {
     }
   }
 
+  // one CAVI iteration (steps A-F); with several ranks the item-side sums are
+  // all-reduced between the local and the replicated half
+  void iterate() {
+    int rc;
+    if (comm.world == 1) { if ((rc = hpf_iterate(h, 1))) die("hpf_iterate", rc); return; }
+    if ((rc = hpf_iterate_local(h))) die("hpf_iterate_local", rc);
+    if (use_rccl) { if ((rc = hpf_allreduce_exchange(h))) die("hpf_allreduce_exchange", rc); }
+    else {
+      void *p; size_t cnt;
+      hpf_exchange_buffer(h, &p, &cnt);
+      xbuf.resize(cnt);
+      if ((rc = hpf_exchange_read(h, xbuf.data(), cnt))) die("hpf_exchange_read", rc);
+      comm_check(comm.allreduce_sum(xbuf.data(), cnt), "host-staged all-reduce");
+      if ((rc = hpf_exchange_write(h, xbuf.data(), cnt))) die("hpf_exchange_write", rc);
+    }
+    if ((rc = hpf_iterate_global(h))) die("hpf_iterate_global", rc);
+  }
+
+  // ---- output of sharded objects: every rank writes its rows to a part
+  // file, rank 0 concatenates them in rank (= row) order
+  std::string part_name(const std::string &path, int r) const { return path + ".part" + std::to_string(r); }
+  void finish_parts(const std::string &path) {
+    if (comm.world == 1) return;
+    comm_check(comm.barrier(), "barrier");
+    if (root()) {
+      FILE *out = fopen(path.c_str(), "w");
+      std::vector<char> buf(1 << 20);
+      for (int r = 0; r < comm.world; ++r) {
+        FILE *in = fopen(part_name(path, r).c_str(), "r");
+        if (!in) continue;
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0) fwrite(buf.data(), 1, got, out);
+        fclose(in);
+        unlink(part_name(path, r).c_str());
+      }
+      fclose(out);
+    }
+    comm_check(comm.barrier(), "barrier");
+  }
+  std::string my_path(const std::string &path) const { return comm.world == 1 ? path : part_name(path, comm.rank); }
+
   // GP*::save_state (gpbase.hh:389-398,743-752,971-980)
-  void save_object(const char *name, hpf_state shape, uint32_t rows, uint32_t cols, bool vec_rate,
-                   const std::vector<uint32_t> &ids) {
+  void save_object(const char *name, hpf_state shape, bool user_side, uint32_t cols, bool vec_rate) {
+    const uint32_t rows = user_side ? hi - lo : m, row0 = user_side ? lo : 0;
+    const std::vector<uint32_t> &ids = user_side ? rt.seq2user : rt.seq2item;
+    const bool mine = user_side || root();       // item-side state is replicated: rank 0 writes it
+    const std::string base = env.file_str(std::string("/") + name);
     std::vector<double> buf;
     auto get = [&](hpf_state w, size_t cnt) {
       buf.resize(cnt);
       int rc = hpf_get_state(h, w, buf.data(), cnt);
       if (rc) die("hpf_get_state", rc);
     };
-    const std::string base = env.file_str(std::string("/") + name);
-    const uint32_t nids = (uint32_t)ids.size();
-    get(shape, (size_t)rows * cols);
-    save_matrix(base + "_shape.tsv", buf.data(), rows, cols, ids.data(), nids);
-    if (vec_rate) {   // GPMatrixGR: D1Array<double>::save of the K-vector, ids looked up by k
-      get((hpf_state)(shape + 1), cols);
-      save_vector(base + "_rate.tsv", buf.data(), cols, ids.data(), nids);
-    } else {
-      get((hpf_state)(shape + 1), (size_t)rows * cols);
-      save_matrix(base + "_rate.tsv", buf.data(), rows, cols, ids.data(), nids);
+    const char *suf[3] = {"_shape.tsv", "_rate.tsv", ".tsv"};
+    for (int j = 0; j < 3; ++j) {
+      const std::string path = base + suf[j];
+      const bool vec = j == 1 && vec_rate;       // GPMatrixGR rate: K-vector, ids looked up by k
+      if (vec) {
+        if (root()) { get((hpf_state)(shape + 1), cols); save_vector(path, buf.data(), cols, ids.data(), (uint32_t)ids.size()); }
+        continue;
+      }
+      if (mine) {
+        get((hpf_state)(shape + j), (size_t)rows * cols);
+        save_matrix(user_side ? my_path(path) : path, buf.data(), rows, cols, ids.data(), (uint32_t)ids.size(), row0);
+      }
+      if (user_side) finish_parts(path);
     }
-    get((hpf_state)(shape + 2), (size_t)rows * cols);
-    save_matrix(base + ".tsv", buf.data(), rows, cols, ids.data(), nids);
   }
-  void save_array(const char *name, hpf_state shape, uint32_t rows, const std::vector<uint32_t> &ids) {
+  void save_array(const char *name, hpf_state shape, bool user_side) {
+    const uint32_t rows = user_side ? hi - lo : m, row0 = user_side ? lo : 0;
+    const std::vector<uint32_t> &ids = user_side ? rt.seq2user : rt.seq2item;
     std::vector<double> buf(rows);
     const std::string base = env.file_str(std::string("/") + name);
     const char *suf[3] = {"_shape.tsv", "_rate.tsv", ".tsv"};
     for (int j = 0; j < 3; ++j) {
-      int rc = hpf_get_state(h, (hpf_state)(shape + j), buf.data(), rows);
-      if (rc) die("hpf_get_state", rc);
-      save_vector(base + suf[j], buf.data(), rows, ids.data(), (uint32_t)ids.size());
+      const std::string path = base + suf[j];
+      if (user_side || root()) {
+        int rc = hpf_get_state(h, (hpf_state)(shape + j), buf.data(), rows);
+        if (rc) die("hpf_get_state", rc);
+        save_vector(user_side ? my_path(path) : path, buf.data(), rows, ids.data(), (uint32_t)ids.size(), row0);
+      }
+      if (user_side) finish_parts(path);
     }
   }
 
   void save_model() {                           // hgaprec.cc:2137-2158
     if (env.hier) {
-      save_object("hbeta", HPF_BETA_SHAPE, m, k, false, rt.seq2item);
-      save_array("betarate", HPF_ETA_SHAPE, m, rt.seq2item);
-      save_object("htheta", HPF_THETA_SHAPE, n, k, false, rt.seq2user);
-      save_array("thetarate", HPF_XI_SHAPE, n, rt.seq2user);
+      save_object("hbeta", HPF_BETA_SHAPE, false, k, false);
+      save_array("betarate", HPF_ETA_SHAPE, false);
+      save_object("htheta", HPF_THETA_SHAPE, true, k, false);
+      save_array("thetarate", HPF_XI_SHAPE, true);
     } else {
-      save_object("beta", HPF_BETA_SHAPE, m, k, true, rt.seq2item);
-      save_object("theta", HPF_THETA_SHAPE, n, k, true, rt.seq2user);
+      save_object("beta", HPF_BETA_SHAPE, false, k, true);
+      save_object("theta", HPF_THETA_SHAPE, true, k, true);
     }
     if (env.bias) {     // n x 1 GPMatrix objects: one value column
-      save_object("betabias", HPF_IBIAS_SHAPE, m, 1, false, rt.seq2item);
-      save_object("thetabias", HPF_UBIAS_SHAPE, n, 1, false, rt.seq2user);
+      save_object("betabias", HPF_IBIAS_SHAPE, false, 1, false);
+      save_object("thetabias", HPF_UBIAS_SHAPE, true, 1, false);
     }
   }
 
@@ -169,32 +265,35 @@ struct Driver {
   bool test_hit(int v) const {                   // ratings.hh:183-189
     return env.binary_data ? v >= 1 : (uint32_t)v >= env.rating_threshold;
   }
-  // rating stored for (user n, item m) in the training set, 0 if absent (Ratings::r)
-  uint32_t train_r(uint32_t n, uint32_t m) const {
+  // rating stored for (global user u, item it) in the training set, 0 if absent (Ratings::r)
+  uint32_t train_r(uint32_t u, uint32_t it) const {
     uint32_t r = 0;                              // duplicates carry the same (last) value
-    for (int64_t j = rt.rowptr[n]; j < rt.rowptr[n + 1]; ++j) if (rt.col[(size_t)j] == m) r = rt.val[(size_t)j];
+    for (int64_t j = rt.rowptr[u]; j < rt.rowptr[u + 1]; ++j) if (rt.col[(size_t)j] == it) r = rt.val[(size_t)j];
     return r;
   }
-  static size_t lower(const HeldOut &h, uint32_t u, uint32_t i) {
-    size_t lo = 0, hi = h.u.size();
-    while (lo < hi) { size_t mid = (lo + hi) / 2;
-      if (h.u[mid] < u || (h.u[mid] == u && h.i[mid] < i)) lo = mid + 1; else hi = mid; }
-    return lo;
+  static size_t lower(const HeldOut &ho, uint32_t u, uint32_t i) {
+    size_t a = 0, b = ho.u.size();
+    while (a < b) { size_t mid = (a + b) / 2;
+      if (ho.u[mid] < u || (ho.u[mid] == u && ho.i[mid] < i)) a = mid + 1; else b = mid; }
+    return a;
   }
-  // validation items of the sampled users, CSR over `sampled` (is_validation())
-  void build_mask(std::vector<uint64_t> &mptr, std::vector<uint32_t> &mitems) const {
-    mptr.assign(sampled.size() + 1, 0); mitems.clear();
-    for (size_t b = 0; b < sampled.size(); ++b) {
-      for (size_t a = lower(rt.validation, sampled[b], 0); a < rt.validation.u.size() && rt.validation.u[a] == sampled[b]; ++a)
+  // this rank's part of the sampled users (local indices) + their validation items (is_validation())
+  void local_sample(std::vector<uint32_t> &lus, std::vector<uint64_t> &mptr, std::vector<uint32_t> &mitems) const {
+    lus.clear(); mitems.clear(); mptr.assign(1, 0);
+    for (uint32_t u : sampled) {
+      if (u < lo || u >= hi) continue;
+      lus.push_back(u - lo);
+      for (size_t a = lower(rt.validation, u, 0); a < rt.validation.u.size() && rt.validation.u[a] == u; ++a)
         mitems.push_back(rt.validation.i[a]);
-      mptr[b + 1] = mitems.size();
+      mptr.push_back(mitems.size());
     }
   }
 
   void compute_precision(bool save_ranking_file) {          // hgaprec.cc:1703-1848
     if (iter % 100 == 0 && iter > 0) save_ranking_file = true;
-    FILE *f = save_ranking_file ? fopen(env.file_str("/ranking.tsv").c_str(), "w") : nullptr;
-    if (!save_ranking_file) {                    // hgaprec.cc:1714-1721
+    const std::string rpath = env.file_str("/ranking.tsv");
+    FILE *f = save_ranking_file ? fopen(my_path(rpath).c_str(), "w") : nullptr;
+    if (!save_ranking_file) {                    // hgaprec.cc:1714-1721 (same draws on every rank)
       sampled.clear();
       do {
         const uint32_t u = (uint32_t)rng.uniform_int(n);
@@ -203,15 +302,15 @@ struct Driver {
       } while (sampled.size() < 1000 && sampled.size() < n / 2);
     }
     const uint32_t N = 100;                      // _topN_by_user
-    std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
-    build_mask(mptr, mitems);
-    std::vector<uint32_t> items(sampled.size() * N); std::vector<double> scores(sampled.size() * N);
-    int rc = hpf_rank_topn(h, sampled.data(), (uint32_t)sampled.size(), mptr.data(), mitems.data(), N,
+    std::vector<uint32_t> lus; std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
+    local_sample(lus, mptr, mitems);
+    std::vector<uint32_t> items(lus.size() * N); std::vector<double> scores(lus.size() * N);
+    int rc = hpf_rank_topn(h, lus.data(), (uint32_t)lus.size(), mptr.data(), mitems.data(), N,
                            items.data(), scores.data());
     if (rc) die("hpf_rank_topn", rc);
-    double mhits10 = 0, mhits100 = 0; uint32_t total_users = 0;
-    for (size_t b = 0; b < sampled.size(); ++b) {
-      const uint32_t u = sampled[b];
+    double acc[3] = {0, 0, 0};                   // mhits10, mhits100, total_users
+    for (size_t b = 0; b < lus.size(); ++b) {
+      const uint32_t u = lus[b] + lo;
       uint32_t hits10 = 0, hits100 = 0;
       for (uint32_t j = 0; j < m && j < N; ++j) {
         const uint32_t it = items[b * N + j]; const double pred = scores[b * N + j];
@@ -224,42 +323,48 @@ struct Driver {
         }
         if (f && train_r(u, it) == 0) fprintf(f, "%d\t%d\t%.5f\t%d\n", rt.seq2user[u], rt.seq2item[it], pred, v);
       }
-      mhits10 += (double)hits10 / 10; mhits100 += (double)hits100 / 100; total_users++;
+      acc[0] += (double)hits10 / 10; acc[1] += (double)hits100 / 100; acc[2] += 1;
     }
     if (f) fclose(f);
-    fprintf(pf, "%d\t%.5f\t%.5f\n", total_users, (double)mhits10 / total_users, (double)mhits100 / total_users);
-    fflush(pf);
+    if (save_ranking_file) finish_parts(rpath);
+    comm_check(comm.allreduce_sum(acc, 3), "precision all-reduce");
+    if (root()) {
+      const uint32_t total_users = (uint32_t)acc[2];
+      fprintf(pf, "%d\t%.5f\t%.5f\n", total_users, (double)acc[0] / total_users, (double)acc[1] / total_users);
+      fflush(pf);
+    }
   }
 
   void compute_itemrank(bool final) {                       // hgaprec.cc:1606-1701
     if (iter % 100 == 0 && iter > 0) final = true;
     if (!final) return;
-    FILE *f = fopen(env.file_str("/itemrank.tsv").c_str(), "w");
-    FILE *itemf = fopen(env.file_str("/meanrank.txt").c_str(), "w");
-    if (!itemf) { printf("cannot open logl file:%s\n", strerror(errno)); exit(-1); }
+    const std::string ipath = env.file_str("/itemrank.tsv");
+    FILE *f = fopen(my_path(ipath).c_str(), "w");
     if (item_deg.empty()) { item_deg.assign(m, 0); for (uint32_t c : rt.col) item_deg[c]++; }
-    std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
-    build_mask(mptr, mitems);
+    std::vector<uint32_t> lus; std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
+    local_sample(lus, mptr, mitems);
     std::vector<uint32_t> qs, qi;                 // one query per test item that is a hit
-    for (size_t b = 0; b < sampled.size(); ++b)
-      for (size_t a = lower(rt.test, sampled[b], 0); a < rt.test.u.size() && rt.test.u[a] == sampled[b]; ++a)
+    for (size_t b = 0; b < lus.size(); ++b) {
+      const uint32_t u = lus[b] + lo;
+      for (size_t a = lower(rt.test, u, 0); a < rt.test.u.size() && rt.test.u[a] == u; ++a)
         if (test_hit(rt.test.y[a])) { qs.push_back((uint32_t)b); qi.push_back(rt.test.i[a]); }
+    }
     std::vector<uint32_t> rank(qs.size()); std::vector<double> pred(qs.size());
-    int rc = hpf_item_ranks(h, sampled.data(), (uint32_t)sampled.size(), mptr.data(), mitems.data(),
+    int rc = hpf_item_ranks(h, lus.data(), (uint32_t)lus.size(), mptr.data(), mitems.data(),
                             qs.data(), qi.data(), (uint32_t)qs.size(), rank.data(), pred.data());
     if (rc) die("hpf_item_ranks", rc);
-    double sum_rank = .0, sum_reciprocal_rank = .0; uint32_t total_users = 0;
+    double acc[3] = {0, 0, 0};                   // sum_rank, sum_reciprocal_rank, total_users
     std::vector<uint32_t> ord, seen;
-    for (size_t b = 0, q0 = 0; b < sampled.size(); ++b) {
+    for (size_t b = 0, q0 = 0; b < lus.size(); ++b) {
       size_t q1 = q0; while (q1 < qs.size() && qs[q1] == b) ++q1;
-      const uint32_t u = sampled[b];
+      const uint32_t u = lus[b] + lo;
       // items the reference counts as "ranked": Ratings::r(n,m) == 0
       seen.clear();
       for (int64_t j = rt.rowptr[u]; j < rt.rowptr[u + 1]; ++j) if (rt.val[(size_t)j] > 0) seen.push_back(rt.col[(size_t)j]);
       std::sort(seen.begin(), seen.end());
       const uint32_t nranked = m - (uint32_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
       ord.resize(q1 - q0);
-      for (size_t k = 0; k < ord.size(); ++k) ord[k] = (uint32_t)(q0 + k);
+      for (size_t t = 0; t < ord.size(); ++t) ord[t] = (uint32_t)(q0 + t);
       std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return rank[x] < rank[y]; });
       double rank_ui = .0, reciprocal_rank_ui = .0; uint32_t ntestitems = 0;
       for (uint32_t q : ord) {
@@ -270,65 +375,82 @@ struct Driver {
         reciprocal_rank_ui += 1 / (j + 1);        // integer division, as in the reference
       }
       if (ntestitems > 0 && nranked > 0) {
-        sum_rank += (rank_ui / nranked) / ntestitems;
-        sum_reciprocal_rank += reciprocal_rank_ui / ntestitems;
-        total_users++;
+        acc[0] += (rank_ui / nranked) / ntestitems;
+        acc[1] += reciprocal_rank_ui / ntestitems;
+        acc[2] += 1;
       }
       q0 = q1;
     }
     fclose(f);
-    fprintf(itemf, "%d\t%.5f\t%.5f\n", total_users, (double)sum_rank / total_users,
-            (double)sum_reciprocal_rank / total_users);
-    fclose(itemf);
+    finish_parts(ipath);
+    comm_check(comm.allreduce_sum(acc, 3), "itemrank all-reduce");
+    if (root()) {
+      FILE *itemf = fopen(env.file_str("/meanrank.txt").c_str(), "w");
+      if (!itemf) { printf("cannot open logl file:%s\n", strerror(errno)); exit(-1); }
+      const uint32_t total_users = (uint32_t)acc[2];
+      fprintf(itemf, "%d\t%.5f\t%.5f\n", total_users, (double)acc[0] / total_users, (double)acc[1] / total_users);
+      fclose(itemf);
+    }
   }
 
   void gen_ranking_for_users() {                            // hgaprec.cc:2087-2112 (load == false)
     const std::string path = env.datfname + "/test_users.tsv";
-    env.lerr("loading test users from %s", path.c_str());
+    if (root()) env.lerr("loading test users from %s", path.c_str());
     std::vector<uint32_t> ids;
-    if (rt.read_test_users(path, &ids)) { env.lerr("cannot open %s", path.c_str()); return; }
+    if (rt.read_test_users(path, &ids)) { if (root()) env.lerr("cannot open %s", path.c_str()); return; }
     sampled = ids;
     compute_precision(true);
     compute_itemrank(true);
-    env.lerr("DONE writing ranking.tsv in output directory\n");
+    if (root()) env.lerr("DONE writing ranking.tsv in output directory\n");
   }
 
   void do_on_stop() { save_model(); gen_ranking_for_users(); }          // hgaprec.cc:1572-1577
 
   // HGAPRec::compute_likelihood (hgaprec.cc:1439-1501); returns true to stop
   bool compute_likelihood(bool validation) {
-    const HeldOut &ho = validation ? rt.validation : rt.test;
-    FILE *ff = validation ? vf : tf;
+    const HeldOut &ho = validation ? lvalid : ltest;
     double s = 0.0; uint64_t cnt = 0;
     int rc = hpf_heldout_ll(h, ho.u.data(), ho.i.data(), ho.y.data(), ho.u.size(), &s, &cnt);
     if (rc) die("hpf_heldout_ll", rc);
-    const uint32_t kk = (uint32_t)cnt;
-    fprintf(ff, "%d\t%d\t%.9f\t%d\n", iter, duration(), s / kk, kk);
-    fflush(ff);
+    double acc[2] = {s, (double)cnt};
+    comm_check(comm.allreduce_sum(acc, 2), "likelihood all-reduce");
+    const uint32_t kk = (uint32_t)acc[1];
+    const double a = acc[0] / kk;
+    if (root()) {
+      FILE *ff = validation ? vf : tf;
+      fprintf(ff, "%d\t%d\t%.9f\t%d\n", iter, duration(), a, kk);
+      fflush(ff);
+    }
     if (!validation) return false;
-    const double a = s / kk;
     int why = -1;
-    const bool st = stop.update(iter, a, &why);
-    FILE *f = fopen(env.file_str("/max.txt").c_str(), "w");
-    fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, duration(), a, why);
-    fclose(f);
+    const bool st = stop.update(iter, a, &why);   // same value on every rank => same decision
+    if (root()) {
+      FILE *f = fopen(env.file_str("/max.txt").c_str(), "w");
+      fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, duration(), a, why);
+      fclose(f);
+    }
     if (st) { do_on_stop(); return true; }
     return false;
+  }
+
+  void finish(int code) {
+    if (h) { hpf_synchronize(h); hpf_destroy(h); h = nullptr; }
+    comm.barrier();
+    comm.close_all();
+    exit(code);
   }
 
   // the three batch loops share one shape; only -hier honours max_iterations
   // (hgaprec.cc:1337-1339; vb() and vb_bias() run until the stop rule fires)
   void run() {
-    if (!env.hier) env.lerr(env.bias ? "running vb_bias()" : "running vb()");
+    if (!env.hier && root()) env.lerr(env.bias ? "running vb_bias()" : "running vb()");
     initialize();
     while (1) {
-      if (env.hier && iter > env.max_iterations) exit(0);
-      int rc = hpf_iterate(h, 1);
-      if (rc) die("hpf_iterate", rc);
-      printf("\r iteration %d", iter);
-      fflush(stdout);
+      if (env.hier && iter > env.max_iterations) finish(0);
+      iterate();
+      if (root()) { printf("\r iteration %d", iter); fflush(stdout); }
       if (iter % env.rfreq == 0) {
-        if (compute_likelihood(true)) exit(0);
+        if (compute_likelihood(true)) finish(0);
         compute_likelihood(false);
         save_model();
         compute_precision(false);
@@ -337,18 +459,50 @@ struct Driver {
           double v = 0.0;
           int rc2 = hpf_elbo(h, &v);
           if (rc2) die("hpf_elbo", rc2);
-          fprintf(af, "%.5f\n", v);
-          fflush(af);
+          comm_check(comm.allreduce_sum(&v, 1), "ELBO all-reduce");
+          if (root()) { fprintf(af, "%.5f\n", v); fflush(af); }
         }
       }
-      if (g_save_state_now) {
-        env.lerr("Saving state at iteration %d duration %d secs", iter, duration());
+      double flag = g_save_state_now ? 1.0 : 0.0;           // SIGTERM on any rank => all save
+      if (comm.world > 1) comm_check(comm.allreduce_max(&flag, 1), "signal all-reduce");
+      if (flag > 0) {
+        if (root()) env.lerr("Saving state at iteration %d duration %d secs", iter, duration());
         do_on_stop();
       }
       iter++;
     }
   }
 };
+
+// -ngpus N without rank variables in the environment: re-execute this binary
+// N times, one process per GPU, and wait for all of them
+int spawn_ranks(int ngpus, char **argv)
+{
+  int port = 20000 + (int)(getpid() % 20000);
+  if (const char *e = getenv("MASTER_PORT")) port = atoi(e);
+  std::vector<pid_t> kids;
+  for (int r = 0; r < ngpus; ++r) {
+    pid_t pid = fork();
+    if (pid < 0) { perror("fork"); return 1; }
+    if (pid == 0) {
+      setenv("HGAPREC_RANK", std::to_string(r).c_str(), 1);
+      setenv("HGAPREC_WORLD", std::to_string(ngpus).c_str(), 1);
+      setenv("HGAPREC_PORT", std::to_string(port).c_str(), 1);
+      execv("/proc/self/exe", argv);
+      perror("execv");
+      _exit(127);
+    }
+    kids.push_back(pid);
+  }
+  int code = 0;
+  for (pid_t p : kids) {
+    int st = 0;
+    waitpid(p, &st, 0);
+    const int c = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+    if (c && !code) code = c;
+  }
+  return code;
+}
 
 }  // namespace
 
@@ -361,7 +515,11 @@ int main(int argc, char **argv)
     exit(0);
   }
   Env env; std::string bad;
-  if (env.parse(argc, argv, true, &bad)) {
+  const bool spawned = getenv("HGAPREC_RANK") != nullptr;
+  int rank = 0, world = 1;
+  if (spawned) { rank = atoi(getenv("HGAPREC_RANK")); world = atoi(getenv("HGAPREC_WORLD")); }
+  else if (getenv("RANK") && getenv("WORLD_SIZE")) { rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE")); }
+  if (env.parse(argc, argv, rank == 0, &bad)) {
     fprintf(stdout, "error: unknown option %s\n", bad.c_str());
     fflush(stdout);
     abort();                                    // the reference asserts (main.cc:227-230)
@@ -369,20 +527,38 @@ int main(int argc, char **argv)
   if (!env.unsupported.empty()) {
     fprintf(stderr, "error: option %s selects a mode outside the MI355X hot-path build "
                     "(supported: -dir -n -m -k -hier -bias -binary-data -rfreq -max-iterations "
-                    "-seed -label -rating-threshold -a -b -c -d)\n", env.unsupported.c_str());
+                    "-seed -label -rating-threshold -logl -a -b -c -d, -ngpus -comm -device)\n", env.unsupported.c_str());
     return 2;
   }
-  if (env.open_output()) { fprintf(stderr, "error: cannot create output directory\n"); abort(); }
+  if (world == 1 && env.ngpus > 1) return spawn_ranks(env.ngpus, argv);
+
+  Comm comm;
+  if (world > 1) {
+    const char *addr = getenv("MASTER_ADDR");
+    int port = 29400;
+    if (const char *e = getenv("HGAPREC_PORT")) port = atoi(e);
+    else if (const char *e2 = getenv("MASTER_PORT")) port = atoi(e2) + 1;   // leave MASTER_PORT to the launcher
+    if (comm.init(rank, world, addr ? addr : "127.0.0.1", port)) {
+      fprintf(stderr, "error: [rank %d] cannot reach rank 0 on port %d\n", rank, port);
+      return 1;
+    }
+    if (!env.device_set) env.device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
+  }
+
+  // rank 0 owns the output directory; the others only ever write part files into it
+  if (rank == 0) {
+    if (env.open_output()) { fprintf(stderr, "error: cannot create output directory\n"); abort(); }
+  } else env.prefix = env.make_prefix();
+  if (comm.barrier()) return 1;
 
   Ratings ratings;
   ratings.cap_n = env.n; ratings.cap_m = env.m;
   ratings.binary = env.binary_data; ratings.rating_threshold = env.rating_threshold;
-  fprintf(stdout, "+ reading ratings dataset from %s\n", env.datfname.c_str());
-  fflush(stdout);
+  if (rank == 0) { fprintf(stdout, "+ reading ratings dataset from %s\n", env.datfname.c_str()); fflush(stdout); }
   int rc = ratings.read_train(env.datfname + "/train.tsv");
   if (rc) exit(-1);
-  env.plog("training ratings", (uint32_t)ratings.nratings);
-  {
+  if (rank == 0) {
+    env.plog("training ratings", (uint32_t)ratings.nratings);
     uint32_t lu = 0, li = 0;
     ratings.write_marginals(env.file_str("/byusers.tsv"), env.file_str("/byitems.tsv"), &lu, &li);
     env.lerr("longest sequence of users with no movies: %d", lu);
@@ -390,18 +566,17 @@ int main(int argc, char **argv)
     // write_marginal_distributions logs env.n / env.m before Ratings::read shrinks them
     env.plog("post pruning nusers:", env.n);
     env.plog("post pruning nitems:", env.m);
-  }
-  {
     char st[1024];
     snprintf(st, sizeof st, "read %d users, %d movies, %d ratings", ratings.n, ratings.m, (uint32_t)ratings.nratings);
     env.plog("statistics", std::string(st));
   }
   if (!env.batch) {
-    printf("Quitting. Online inference not implemented.\n");
-    fflush(stdout);
+    if (rank == 0) { printf("Quitting. Online inference not implemented.\n"); fflush(stdout); }
     exit(0);
   }
-  Driver d(env, ratings);
+  if ((uint32_t)world > ratings.n) { fprintf(stderr, "error: more ranks than users\n"); return 1; }
+  Driver d(env, ratings, comm);
+  d.use_rccl = world > 1 && env.comm_mode != "host";
   d.construct();
   d.run();
   return 0;

@@ -12,6 +12,8 @@
 #include "../../include/hpf.h"
 #include "hpf_kernels.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -79,8 +81,43 @@ struct hpf_handle {
   hipEvent_t evr[RING][7] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
   uint32_t ev_count = 0;                        // iterations recorded so far
+  void *comm = nullptr;                 // ncclComm_t once hpf_comm_init succeeded
   std::string err;
 };
+
+// ---- RCCL, loaded at run time (one process per GPU; the library must not
+// depend on librccl at link time: single-GPU users never load it) -------------
+namespace {
+struct IdByValue { char internal[HPF_COMM_ID_BYTES]; };   // layout of ncclUniqueId (rccl.h:43)
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, IdByValue /* ncclUniqueId by value */, int) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, void *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+const char *load_rccl()
+{
+  if (g_rccl.lib) return nullptr;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void *lib = nullptr;
+  for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!lib) return "cannot dlopen librccl.so";
+  RcclApi a; a.lib = lib;
+  a.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (int (*)(void **, int, IdByValue, int))dlsym(lib, "ncclCommInitRank");
+  a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, void *))dlsym(lib, "ncclAllReduce");
+  a.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+  a.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
+    return "librccl.so lacks an expected symbol";
+  g_rccl = a;
+  return nullptr;
+}
+}  // namespace
 
 namespace {
 
@@ -653,6 +690,7 @@ void hpf_destroy(hpf_handle *h)
 {
   if (!h) return;
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
   h->u.colsum = nullptr;
   double *icol = h->it.colsum; h->it.colsum = nullptr;
@@ -679,6 +717,51 @@ int hpf_bind_exchange_buffer(hpf_handle *h, void *dev, size_t count)
   if (!h->exch_external) dfree(h->exch);
   h->exch = (double *)dev; h->exch_external = true;
   h->it.S = h->exch; h->u.colsum = h->exch + (size_t)h->it.rows * h->ld;
+  return HPF_OK;
+}
+
+int hpf_comm_unique_id(void *id_out)
+{
+  if (!id_out) return HPF_ERR_INVALID;
+  if (load_rccl()) return HPF_ERR_UNSUPPORTED;
+  return g_rccl.GetUniqueId(id_out) == 0 ? HPF_OK : HPF_ERR_HIP;
+}
+
+int hpf_comm_init(hpf_handle *h, const void *id)
+{
+  if (!h || !id) return HPF_ERR_INVALID;
+  if (h->comm) { h->err = "communicator already initialised"; return HPF_ERR_INVALID; }
+  if (const char *e = load_rccl()) { h->err = e; return HPF_ERR_UNSUPPORTED; }
+  IdByValue v; memcpy(v.internal, id, HPF_COMM_ID_BYTES);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const int rc = g_rccl.CommInitRank(&h->comm, (int)h->cfg.n_ranks, v, (int)h->cfg.rank);
+  if (rc != 0) { h->comm = nullptr; h->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
+  return HPF_OK;
+}
+
+int hpf_allreduce_exchange(hpf_handle *h)
+{
+  if (!h) return HPF_ERR_INVALID;
+  if (!h->comm) { h->err = "hpf_comm_init has not been called"; return HPF_ERR_STATE; }
+  // ncclDouble = 8, ncclSum = 0 (rccl.h:448,467); in place, on the stream the kernels use
+  const int rc = g_rccl.AllReduce(h->exch, h->exch, h->exch_count, 8, 0, h->comm, (void *)h->stream);
+  if (rc != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
+  return HPF_OK;
+}
+
+int hpf_exchange_read(hpf_handle *h, double *host, size_t count)
+{
+  if (!h || !host || count != h->exch_count) return HPF_ERR_INVALID;
+  HIPCHK(h, hipMemcpyAsync(host, h->exch, count * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
+int hpf_exchange_write(hpf_handle *h, const double *host, size_t count)
+{
+  if (!h || !host || count != h->exch_count) return HPF_ERR_INVALID;
+  HIPCHK(h, hipMemcpyAsync(h->exch, host, count * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return HPF_OK;
 }
 

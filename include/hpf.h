@@ -147,6 +147,20 @@ int  hpf_bind_exchange_buffer(hpf_handle *h, void *device_ptr, size_t count);
 /* ... then the replicated item sweep (C, D-item, F) on every rank. */
 int  hpf_iterate_global(hpf_handle *h);
 
+/* The library can run that all-reduce itself: RCCL is dlopen'ed on first use
+ * (no link-time dependency).  One rank calls hpf_comm_unique_id and ships the
+ * HPF_COMM_ID_BYTES bytes to the others by any means; every rank then calls
+ * hpf_comm_init (collective) once, and hpf_allreduce_exchange between
+ * iterate_local and iterate_global.  = ncclGetUniqueId / ncclCommInitRank /
+ * ncclAllReduce(ncclDouble, ncclSum) in place on the handle's stream. */
+#define HPF_COMM_ID_BYTES 128
+int  hpf_comm_unique_id(void *id_out);
+int  hpf_comm_init(hpf_handle *h, const void *id);
+int  hpf_allreduce_exchange(hpf_handle *h);
+/* host copies of the exchange buffer (host-staged reduction, tests) */
+int  hpf_exchange_read(hpf_handle *h, double *host, size_t count);
+int  hpf_exchange_write(hpf_handle *h, const double *host, size_t count);
+
 /* replaces: the per-pair loop of HGAPRec::compute_likelihood
  * (hgaprec.cc:1455-1465) with rating_likelihood_hier / rating_likelihood
  * (1538-1560 / 1503-1536).  u is a LOCAL user index, y the int stored in the

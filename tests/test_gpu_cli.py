@@ -133,3 +133,61 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
                          "mle_user", "mle_item"]
     assert keys[20:27] == ["training ratings", "post pruning nusers", "post pruning nitems", "statistics",
                            "infer n", "test ratings", "validation ratings"]
+
+
+@pytest.mark.parametrize("flags,K,maxit", [
+    (["-hier", "-bias", "-logl"], 6, 12),
+    ([], 5, None),                 # vb(): stop rule -> do_on_stop -> gen_ranking_for_users on every rank
+    (["-hier", "-rfreq", "50"], 5, 100),
+])
+def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
+    """`-ngpus 2`: two processes (here both on GPU 0, all-reduce staged through
+    the host: `-comm host`), users sharded by nnz; the output directory must be
+    what the single-process reference semantics give."""
+    n, m = 300, 200
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    hier, bias = "-hier" in flags, "-bias" in flags
+    logl = "-logl" in flags
+    rfreq = 2 if hier else 10
+    if "-rfreq" in flags:
+        rfreq = int(flags[flags.index("-rfreq") + 1])
+        flags = [f for k, f in enumerate(flags) if f != "-rfreq" and (k == 0 or flags[k - 1] != "-rfreq")]
+    if not hier:
+        ids = sorted({int(l.split("\t")[0]) for l in (data / "test.tsv").read_text().splitlines()})
+        (data / "test_users.tsv").write_text("".join(f"{u}\n" for u in ids[:60]))
+    args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "7", "-rfreq", str(rfreq)] + flags
+    if maxit is not None:
+        args += ["-max-iterations", str(maxit)]
+    r = subprocess.run([str(EXE)] + args + ["-ngpus", "2", "-device", "0", "-comm", "host"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    outs = [p for p in tmp_path.iterdir() if p.is_dir() and p.name.startswith(f"n{n}-m{m}-k{K}")]
+    assert len(outs) == 1
+    out = outs[0]
+    assert not [p for p in out.iterdir() if ".part" in p.name]          # all part files merged
+    ref = tmp_path / "oracle_out"
+    ref.mkdir()
+    orc.run(data, ref, n, m, K, hier=hier, bias=bias, rfreq=rfreq,
+            max_iterations=maxit if maxit is not None else 1000, seed=7, logl=logl)
+    for f in ("validation.txt", "test.txt"):
+        a, b = series(out / f), series(ref / f)
+        assert [x[0] for x in a] == [x[0] for x in b] and [x[2] for x in a] == [x[2] for x in b]
+        assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    assert (out / "precision.txt").read_text() == (ref / "precision.txt").read_text()
+    for f in ("ranking.tsv", "itemrank.tsv", "meanrank.txt"):
+        assert (out / f).exists() == (ref / f).exists(), f
+        if (ref / f).exists():
+            assert (out / f).read_text() == (ref / f).read_text(), f
+    la = [float(x) for x in (out / "logl.txt").read_text().split()]
+    lb = [float(x) for x in (ref / "logl.txt").read_text().split()]
+    assert len(la) == len(lb) and all(abs(x - y) <= 2e-5 + 1e-10 * abs(y) for x, y in zip(la, lb))
+    names = (["hbeta", "htheta", "betarate", "thetarate"] if hier else ["beta", "theta"])
+    if bias:
+        names += ["betabias", "thetabias"]
+    for nm in names:
+        for suf in ("", "_shape", "_rate"):
+            ia, va = read_tsv(out / f"{nm}{suf}.tsv")
+            ib, vb = read_tsv(ref / f"{nm}{suf}.tsv")
+            assert np.array_equal(ia, ib), nm + suf
+            assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf

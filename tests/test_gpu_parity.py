@@ -234,3 +234,18 @@ def test_hot_cold_two_phase_pass(orc, monkeypatch, bias):
     for w in compare_states(True, bias):
         assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
     assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
+
+
+def test_library_rccl_allreduce_world1(orc):
+    # the dlopen'ed RCCL path on real hardware: a 1-rank communicator, in-place
+    # sum all-reduce of the exchange buffer (a no-op numerically)
+    from hgaprec_amd.capi import Hpf
+    M, D = _run_pair(orc, 80, 60, 6, 900, True, False, False, 1, seed=2)
+    D.iterate(1)
+    before = D.exchange_read()
+    D.comm_init(Hpf.comm_unique_id())
+    D.allreduce_exchange()
+    D.synchronize()
+    assert np.array_equal(D.exchange_read(), before)
+    D.exchange_write(before * 2.0)
+    assert np.array_equal(D.exchange_read(), before * 2.0)

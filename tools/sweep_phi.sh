@@ -1,3 +1,3 @@
-for cfg in "16,7" "32,4" "64,2" "16,8" "32,5"; do
-  HPF_SWEEP_CFG=$cfg python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('sweep $cfg', round(d['value']/1e9,3), d['kernels_ms'])"
+for m in 2000 5000 20000 100000; do
+  python bench.py --m $m --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('m=$m nnz', d['config']['nnz_total'], round(d['value']/1e9,3), d['kernels_ms'])"
 done
