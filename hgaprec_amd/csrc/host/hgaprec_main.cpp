@@ -494,12 +494,21 @@ int spawn_ranks(int ngpus, char **argv)
     }
     kids.push_back(pid);
   }
-  int code = 0;
-  for (pid_t p : kids) {
+  // wait for all; if one rank fails, the others may be blocked in a collective
+  // waiting for it: terminate them instead of hanging
+  int code = 0; size_t left = kids.size();
+  while (left) {
     int st = 0;
-    waitpid(p, &st, 0);
+    const pid_t p = waitpid(-1, &st, 0);
+    if (p < 0) { if (errno == EINTR) continue; break; }
+    auto it = std::find(kids.begin(), kids.end(), p);
+    if (it == kids.end()) continue;
+    *it = -1; --left;
     const int c = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
-    if (c && !code) code = c;
+    if (c && !code) {
+      code = c;
+      for (pid_t q : kids) if (q > 0) kill(q, SIGKILL);
+    }
   }
   return code;
 }
