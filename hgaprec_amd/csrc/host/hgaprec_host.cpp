@@ -522,21 +522,75 @@ void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hie
 // ======================================================================
 // writers
 // ======================================================================
+// "%.8f" without printf: exact for 0 <= |v| < 2^53 (everything this model
+// produces), falls back to snprintf otherwise.  The integer part is exact;
+// the fraction f = v - floor(v) is exact too, and f * 1e8 is formed as an
+// error-free product p + e (e = fma(f, 1e8, -p)), so the decimal is rounded
+// exactly like glibc does it: to nearest, ties to even.
+size_t format_fixed8(double v, char *out)
+{
+  if (!(std::fabs(v) < 9007199254740992.0)) return (size_t)snprintf(out, 400, "%.8f", v);   // also NaN
+  char *o = out;
+  if (std::signbit(v)) { *o++ = '-'; v = -v; }
+  double ipd = std::floor(v);
+  const double f = v - ipd;                        // exact
+  const double p = f * 1e8, e = std::fma(f, 1e8, -p);
+  double n = std::nearbyint(p);                    // ties to even on p
+  // r = p - n is exact and |r| <= 0.5; |e| < ulp(p), so the true product
+  // p + e can only be on the other side of a rounding boundary when |r| == 0.5
+  const double r = p - n;
+  if (r == 0.5) { if (e > 0.0 || (e == 0.0 && std::fmod(n, 2.0) != 0.0)) n += 1.0; }
+  else if (r == -0.5) { if (e < 0.0 || (e == 0.0 && std::fmod(n, 2.0) != 0.0)) n -= 1.0; }
+  if (n >= 1e8) { n -= 1e8; ipd += 1.0; }
+  uint64_t ip = (uint64_t)ipd; uint32_t fr = (uint32_t)n;
+  char tmp[24]; int len = 0;
+  do { tmp[len++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+  while (len) *o++ = tmp[--len];
+  *o++ = '.';
+  for (int k = 7; k >= 0; --k) { o[k] = (char)('0' + fr % 10); fr /= 10; }
+  o += 8;
+  return (size_t)(o - out);
+}
+
+namespace {
+inline char *put_u32(char *o, uint32_t v)           // "%d" of a value below 2^31 (seq ids, item ids)
+{
+  if ((int32_t)v < 0) return o + sprintf(o, "%d", (int32_t)v);
+  char tmp[12]; int len = 0;
+  do { tmp[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (len) *o++ = tmp[--len];
+  return o;
+}
+struct BufWriter {
+  FILE *f; std::vector<char> buf; size_t pos = 0;
+  explicit BufWriter(FILE *ff) : f(ff), buf(4u << 20) {}
+  char *room(size_t n) { if (pos + n > buf.size()) flush(); return buf.data() + pos; }
+  void advance(size_t n) { pos += n; }
+  void flush() { if (pos) fwrite(buf.data(), 1, pos, f); pos = 0; }
+};
+}  // namespace
+
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
                 const uint32_t *seq2id, uint32_t nids, uint32_t row0)
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
-  std::vector<char> big(1 << 20);
-  setvbuf(tf, big.data(), _IOFBF, big.size());
+  BufWriter w(tf);
   for (uint32_t i = 0; i < rows; ++i) {
     const uint32_t seq = i + row0;
     const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
-    fprintf(tf, "%d\t", seq);
-    fprintf(tf, "%d\t", id);
-    for (uint32_t k = 0; k < cols; ++k)
-      fprintf(tf, (k == cols - 1) ? "%.8f\n" : "%.8f\t", a[(size_t)i * cols + k]);
+    char *o = w.room(32), *o0 = o;
+    o = put_u32(o, seq); *o++ = '\t';
+    o = put_u32(o, id); *o++ = '\t';
+    w.advance((size_t)(o - o0));
+    for (uint32_t k = 0; k < cols; ++k) {
+      o = w.room(420); o0 = o;
+      o += format_fixed8(a[(size_t)i * cols + k], o);
+      *o++ = (k == cols - 1) ? '\n' : '\t';
+      w.advance((size_t)(o - o0));
+    }
   }
+  w.flush();
   fclose(tf);
   return 0;
 }
@@ -546,13 +600,18 @@ int save_vector(const std::string &path, const double *a, uint32_t rows,
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
+  BufWriter w(tf);
   for (uint32_t i = 0; i < rows; ++i) {
     const uint32_t seq = i + row0;
     const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
-    fprintf(tf, "%d\t", seq);
-    fprintf(tf, "%d\t", id);
-    fprintf(tf, "%.8f\n", a[i]);
+    char *o = w.room(460), *o0 = o;
+    o = put_u32(o, seq); *o++ = '\t';
+    o = put_u32(o, id); *o++ = '\t';
+    o += format_fixed8(a[i], o);
+    *o++ = '\n';
+    w.advance((size_t)(o - o0));
   }
+  w.flush();
   fclose(tf);
   return 0;
 }

@@ -139,6 +139,8 @@ Mt19937 make_rng(double env_seed);
 // ------------------------------------------------------------ writers -----
 // D2Array<double>::save / D1Array<double>::save: "seq\tid\tv...\n", %.8f;
 // id = seq2id[row] when row < nids else the row index itself
+// "%.8f" exactly as printf rounds it, ~10x faster; returns the length (no NUL)
+size_t format_fixed8(double v, char *out);
 // row0: sequence number of the first row (a rank writing its shard of a matrix)
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
                 const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0);

@@ -95,6 +95,14 @@ int hg_save_matrix(const char *path, const double *a, uint32_t rows, uint32_t co
 int hg_save_vector(const char *path, const double *a, uint32_t rows, const uint32_t *ids, uint32_t nids)
 { return save_vector(path, a, rows, ids, nids); }
 
+// format_fixed8 over an array; out receives the strings separated by '\n'
+size_t hg_format_fixed8(const double *v, size_t n, char *out)
+{
+  char *o = out;
+  for (size_t i = 0; i < n; ++i) { o += format_fixed8(v[i], o); *o++ = '\n'; }
+  return (size_t)(o - out);
+}
+
 // feed a validation series through the stop rule; returns the index at which
 // it stops (or -1), why[] receives the max.txt code per step
 int hg_stop_rule(const uint32_t *iters, const double *a, uint32_t cnt, int *why)

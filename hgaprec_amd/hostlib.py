@@ -50,6 +50,8 @@ def lib():
     L.hg_state_get.argtypes = [vp, C.c_int, C.POINTER(dp)]; L.hg_state_get.restype = C.c_size_t
     L.hg_save_matrix.argtypes = [C.c_char_p, dp, C.c_uint32, C.c_uint32, u32p, C.c_uint32]
     L.hg_save_vector.argtypes = [C.c_char_p, dp, C.c_uint32, u32p, C.c_uint32]
+    L.hg_format_fixed8.argtypes = [dp, C.c_size_t, C.c_char_p]
+    L.hg_format_fixed8.restype = C.c_size_t
     L.hg_stop_rule.argtypes = [u32p, dp, C.c_uint32, C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -173,6 +175,14 @@ def save_vector(path, a, ids=None):
     return lib().hg_save_vector(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0],
                                 None if i is None else i.ctypes.data_as(C.POINTER(C.c_uint32)),
                                 0 if i is None else i.size)
+
+
+def format_fixed8(values):
+    """the writers' "%.8f" (exact, printf-compatible) for an array -> list of str"""
+    a = np.ascontiguousarray(values, np.float64)
+    buf = C.create_string_buffer(a.size * 420 + 16)
+    n = lib().hg_format_fixed8(a.ctypes.data_as(C.POINTER(C.c_double)), a.size, buf)
+    return buf.raw[:n].decode().split("\n")[:-1]
 
 
 def stop_rule(iters, series):

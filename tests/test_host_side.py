@@ -228,3 +228,21 @@ def test_stop_rule():
     a = np.array([-3.0, -2.0, -2.1, -2.2, -2.3, -2.25, -2.4, -2.5, -2.45, -2.6])
     at, why = hostlib.stop_rule(it, a)
     assert at == -1                              # an increase resets the counter
+
+
+def test_fast_fixed8_formatter_equals_printf():
+    """the TSV writers format "%.8f" themselves (error-free product + exact
+    tie handling); it must agree with printf on every double, ties included"""
+    rng = np.random.default_rng(11)
+    vals = [0.0, 0.3, 1.0, 0.001953125, 0.005859375, 1.5e-9, 4.999999999e-9, 5e-9, 0.99999999, 0.999999995,
+            0.9999999949999999, 12345.678901234567, 1e-30, 2.5e-9, 7.5e-9, 123456789.0, 1e15 + 0.5,
+            9007199254740991.0, 1e16, 1e300, float("inf"), float("nan"), -0.5, -1e-12, 8191.00000001]
+    vals += [k / 512.0 for k in range(1, 64, 2)]                      # exact ties at the 8th decimal
+    vals += [(2 * k + 1) * 390625 / 2.0 ** 27 for k in range(40)]
+    arr = np.concatenate([np.array(vals), rng.gamma(0.3, 1.0, 200000), rng.random(200000) * 1e-6,
+                          rng.random(100000) * 1e5, np.exp(rng.normal(0, 8, 200000)),
+                          np.round(rng.random(100000), 8) + rng.integers(-3, 4, 100000) * 2.0 ** -60])
+    got = hostlib.format_fixed8(arr)
+    assert len(got) == arr.size
+    for v, g in zip(arr.tolist(), got):
+        assert g == "%.8f" % v, (v.hex() if v == v else v, g, "%.8f" % v)
