@@ -527,27 +527,40 @@ void initialize_state(Mt19937 &rng, uint32_t n, uint32_t m, uint32_t k, bool hie
 // the fraction f = v - floor(v) is exact too, and f * 1e8 is formed as an
 // error-free product p + e (e = fma(f, 1e8, -p)), so the decimal is rounded
 // exactly like glibc does it: to nearest, ties to even.
+namespace {
+const char DIGITS2[201] =
+  "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+  "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+  "8081828384858687888990919293949596979899";
+}
+
 size_t format_fixed8(double v, char *out)
 {
   if (!(std::fabs(v) < 9007199254740992.0)) return (size_t)snprintf(out, 400, "%.8f", v);   // also NaN
   char *o = out;
   if (std::signbit(v)) { *o++ = '-'; v = -v; }
-  double ipd = std::floor(v);
-  const double f = v - ipd;                        // exact
-  const double p = f * 1e8, e = std::fma(f, 1e8, -p);
-  double n = std::nearbyint(p);                    // ties to even on p
+  uint64_t ip = (uint64_t)v;                        // floor(v), v >= 0
+  const double f = v - (double)ip;                  // exact
+  // error-free product f * 1e8 = p + e (Dekker / Veltkamp, no FMA needed):
+  // 1e8 = 1e8 + 0 splits trivially (it has 20 significant bits)
+  const double p = f * 1e8;
+  const double c = 134217729.0 * f, fh = c - (c - f), fl = f - fh;
+  const double e = (fh * 1e8 - p) + fl * 1e8;
+  long n = __builtin_lrint(p);                      // to nearest, ties to even, on p
   // r = p - n is exact and |r| <= 0.5; |e| < ulp(p), so the true product
   // p + e can only be on the other side of a rounding boundary when |r| == 0.5
-  const double r = p - n;
-  if (r == 0.5) { if (e > 0.0 || (e == 0.0 && std::fmod(n, 2.0) != 0.0)) n += 1.0; }
-  else if (r == -0.5) { if (e < 0.0 || (e == 0.0 && std::fmod(n, 2.0) != 0.0)) n -= 1.0; }
-  if (n >= 1e8) { n -= 1e8; ipd += 1.0; }
-  uint64_t ip = (uint64_t)ipd; uint32_t fr = (uint32_t)n;
+  const double r = p - (double)n;
+  if (r == 0.5) { if (e > 0.0 || (e == 0.0 && (n & 1))) n += 1; }
+  else if (r == -0.5) { if (e < 0.0 || (e == 0.0 && (n & 1))) n -= 1; }
+  if (n >= 100000000L) { n -= 100000000L; ip += 1; }
   char tmp[24]; int len = 0;
-  do { tmp[len++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+  while (ip >= 100) { const unsigned q = (unsigned)(ip % 100); ip /= 100; tmp[len++] = DIGITS2[2 * q + 1]; tmp[len++] = DIGITS2[2 * q]; }
+  if (ip >= 10) { tmp[len++] = DIGITS2[2 * ip + 1]; tmp[len++] = DIGITS2[2 * ip]; }
+  else tmp[len++] = (char)('0' + ip);
   while (len) *o++ = tmp[--len];
   *o++ = '.';
-  for (int k = 7; k >= 0; --k) { o[k] = (char)('0' + fr % 10); fr /= 10; }
+  uint32_t fr = (uint32_t)n;
+  for (int k = 3; k >= 0; --k) { const uint32_t q = fr % 100; fr /= 100; o[2 * k] = DIGITS2[2 * q]; o[2 * k + 1] = DIGITS2[2 * q + 1]; }
   o += 8;
   return (size_t)(o - out);
 }
