@@ -249,3 +249,51 @@ def test_library_rccl_allreduce_world1(orc):
     assert np.array_equal(D.exchange_read(), before)
     D.exchange_write(before * 2.0)
     assert np.array_equal(D.exchange_read(), before * 2.0)
+
+
+@pytest.mark.parametrize("K,bias", [(1, False), (1, True), (2, False), (333, False), (512, False), (510, True)])
+def test_extreme_factor_counts(orc, K, bias):
+    n, m = 40, 30
+    M, D = _run_pair(orc, n, m, K, 400, True, bias, False, 2, seed=K)
+    M.iterate(2)
+    D.iterate(2)
+    for w in compare_states(True, bias):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+
+
+def test_unsupported_and_invalid_inputs_fail_loudly():
+    from hgaprec_amd.capi import Hpf, HpfError
+    with pytest.raises(HpfError):
+        Hpf(10, 10, 513)                         # K > HPF_MAX_COLUMNS
+    with pytest.raises(HpfError):
+        Hpf(10, 10, 511, bias=True)              # K + 2 > HPF_MAX_COLUMNS
+    D = Hpf(4, 3, 2)
+    with pytest.raises(HpfError):
+        D.iterate(1)                             # no CSR, no state
+    with pytest.raises(HpfError):
+        D.upload_csr(np.array([0, 1, 2, 3, 4]), np.array([0, 1, 2, 7], np.uint32))   # item 7 out of range
+    with pytest.raises(HpfError):
+        D.upload_csr(np.array([0, 2, 1, 3, 4]), np.array([0, 1, 2, 1], np.uint32))   # rowptr not monotone
+    D.upload_csr(np.array([0, 1, 2, 3, 4]), np.array([0, 1, 2, 1], np.uint32))
+    with pytest.raises(HpfError):
+        D.iterate(1)                             # state never set
+    with pytest.raises(HpfError):
+        D.elbo()
+    with pytest.raises(HpfError):
+        D.heldout_ll(np.array([9], np.uint32), np.array([0], np.uint32), np.array([1], np.int32))
+
+
+def test_single_user_and_no_nonzeros(orc):
+    from hgaprec_amd.capi import Hpf
+    for rp, col in ((np.array([0, 3]), np.array([0, 1, 2], np.uint32)), (np.array([0, 0]), np.zeros(0, np.uint32))):
+        val = np.full(col.size, 2, np.uint8)
+        M = orc.Model(1, 3, 4, True, False, False)
+        M.set_csr(rp, col, val)
+        M.initialize(1)
+        D = Hpf(1, 3, 4)
+        D.upload_csr(rp, col, val)
+        copy_state(M, D, True, False)
+        M.iterate(2)
+        D.iterate(2)
+        for w in compare_states(True, False):
+            assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
