@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--m", type=int, default=0, help="override items (experiments)")
     ap.add_argument("--nnz", type=int, default=0, help="override nonzeros (experiments)")
     ap.add_argument("--K", type=int, default=0, help="override factors (experiments)")
+    ap.add_argument("--w32", action="store_true",
+                    help="EXPERIMENTAL storage mode: W kept in fp32 (arithmetic/accumulators fp64); "
+                         "drifts out of the 1e-4 contract after ~30 iterations -- NOT the headline configuration")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
                          "single-GPU smoke test of the N>1 code path)")
@@ -113,7 +116,7 @@ def main():
     for k in ("n", "m", "nnz", "K"):
         if getattr(args, k):
             cfg[k] = getattr(args, k)
-    custom = args.scale != 1.0 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
+    custom = args.scale != 1.0 or args.w32 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
     n_loc, m, K = cfg["n"], cfg["m"], cfg["K"]
 
     # ---- synthetic shard (generated on the GPU, handed over as host CSR)
@@ -127,7 +130,7 @@ def main():
 
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
             device=local_rank, stream=stream.cuda_stream, n_ranks=world, rank=rank,
-            n_users_total=n_loc * world)
+            n_users_total=n_loc * world, w_storage=1 if args.w32 else 0)
     xbuf = None
     if world > 1:
         xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
@@ -220,7 +223,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else "f64", "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: synthetic power-law ratings, {n_loc} users x {m} items "
                             f"and {nnz_loc} nonzeros per GPU, K={K}, "

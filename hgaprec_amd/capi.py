@@ -44,7 +44,7 @@ class HpfConfig(C.Structure):
         ("struct_size", C.c_uint32), ("n_users", C.c_uint32), ("n_items", C.c_uint32),
         ("K", C.c_uint32), ("hier", C.c_uint32), ("bias", C.c_uint32),
         ("binary", C.c_uint32), ("n_users_total", C.c_uint32), ("device", C.c_int32),
-        ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("reserved0", C.c_uint32),
+        ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("w_storage", C.c_uint32),
         ("stream", C.c_void_p), ("s_prior", C.c_double), ("r_prior", C.c_double),
     ]
 
@@ -124,7 +124,7 @@ class Hpf:
 
     def __init__(self, n_users, n_items, K, hier=True, bias=False, binary=False,
                  device=0, stream=None, n_ranks=1, rank=0, n_users_total=0,
-                 s_prior=0.3, r_prior=0.3):
+                 s_prior=0.3, r_prior=0.3, w_storage=0):
         self.lib = load_library()
         cfg = HpfConfig()
         cfg.struct_size = C.sizeof(HpfConfig)
@@ -134,6 +134,7 @@ class Hpf:
         cfg.device, cfg.n_ranks, cfg.rank = int(device), int(n_ranks), int(rank)
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.s_prior, cfg.r_prior = float(s_prior), float(r_prior)
+        cfg.w_storage = int(w_storage)
         self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(K)
         self.hier, self.bias, self.binary = bool(hier), bool(bias), bool(binary)
         self._h = C.c_void_p()

@@ -28,7 +28,8 @@ namespace {
 
 struct Side {
   uint32_t rows = 0;
-  double *S = nullptr, *E = nullptr, *L = nullptr, *W = nullptr;
+  double *S = nullptr, *E = nullptr, *L = nullptr;
+  void *W = nullptr;                   // [rows x ld] double, or float in the f32-storage mode
   double *prior_E = nullptr, *prior_used = nullptr, *prior_rate = nullptr;
   double *prior_elog = nullptr, *prior_elog_used = nullptr;   // Elog xi/eta now / as used by the last rate
   double *colsum = nullptr;       // [ld] sum over this side's rows of E
@@ -61,6 +62,8 @@ struct Side {
 struct hpf_handle {
   hpf_config cfg;
   uint32_t K = 0, C = 0, ld = 0;
+  bool w32 = false;                     // W stored as float (hpf_config.w_storage = 1)
+  uint32_t *flags = nullptr;            // device word: bit 0 = a softmax denominator underflowed
   hipStream_t stream = nullptr;
   bool own_stream = false;
   Side u, it;
@@ -172,46 +175,46 @@ bool choose_cfg(uint32_t ld, int V, int *G, int *R)
 }
 
 // ---- kernel dispatch over the template grid -------------------------------
-template <int G, int R, int V>
+template <typename WT, int G, int R, int V>
 void launch_phi_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  switch (side) {
-    case 0: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 0>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 1>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((phi_pass_kernel<G, R, V, 3>), dim3(blocks), dim3(256), 0, st, a); break;
-  }
+  if (side & 1) hipLaunchKernelGGL((phi_pass_kernel<WT, G, R, V, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else          hipLaunchKernelGGL((phi_pass_kernel<WT, G, R, V, 0>), dim3(blocks), dim3(256), 0, st, a);
 }
-template <int G, int V>
+template <typename WT, int G, int V>
 bool launch_phi_r(int R, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (R) {
-    case 1: launch_phi_t<G, 1, V>(side, a, blocks, st); return true;
-    case 2: launch_phi_t<G, 2, V>(side, a, blocks, st); return true;
-    case 3: launch_phi_t<G, 3, V>(side, a, blocks, st); return true;
-    case 4: launch_phi_t<G, 4, V>(side, a, blocks, st); return true;
-    case 5: launch_phi_t<G, 5, V>(side, a, blocks, st); return true;
-    case 6: launch_phi_t<G, 6, V>(side, a, blocks, st); return true;
-    case 7: launch_phi_t<G, 7, V>(side, a, blocks, st); return true;
-    case 8: launch_phi_t<G, 8, V>(side, a, blocks, st); return true;
+    case 1: launch_phi_t<WT, G, 1, V>(side, a, blocks, st); return true;
+    case 2: launch_phi_t<WT, G, 2, V>(side, a, blocks, st); return true;
+    case 3: launch_phi_t<WT, G, 3, V>(side, a, blocks, st); return true;
+    case 4: launch_phi_t<WT, G, 4, V>(side, a, blocks, st); return true;
+    case 5: launch_phi_t<WT, G, 5, V>(side, a, blocks, st); return true;
+    case 6: launch_phi_t<WT, G, 6, V>(side, a, blocks, st); return true;
+    case 7: launch_phi_t<WT, G, 7, V>(side, a, blocks, st); return true;
+    case 8: launch_phi_t<WT, G, 8, V>(side, a, blocks, st); return true;
   }
   return false;
 }
-template <int V>
+template <typename WT, int V>
 bool launch_phi_g(int G, int R, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_phi_r<4, V>(R, side, a, blocks, st);
-    case 8:  return launch_phi_r<8, V>(R, side, a, blocks, st);
-    case 16: return launch_phi_r<16, V>(R, side, a, blocks, st);
-    case 32: return launch_phi_r<32, V>(R, side, a, blocks, st);
-    case 64: return launch_phi_r<64, V>(R, side, a, blocks, st);
+    case 4:  return launch_phi_r<WT, 4, V>(R, side, a, blocks, st);
+    case 8:  return launch_phi_r<WT, 8, V>(R, side, a, blocks, st);
+    case 16: return launch_phi_r<WT, 16, V>(R, side, a, blocks, st);
+    case 32: return launch_phi_r<WT, 32, V>(R, side, a, blocks, st);
+    case 64: return launch_phi_r<WT, 64, V>(R, side, a, blocks, st);
   }
   return false;
 }
-bool launch_phi(int G, int R, int V, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+// V = elements per load: 1 or 2 doubles, 2 or 4 floats (8- or 16-byte accesses)
+bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  return V == 2 ? launch_phi_g<2>(G, R, side, a, blocks, st) : launch_phi_g<1>(G, R, side, a, blocks, st);
+  if (w32) return V == 4 ? launch_phi_g<float, 4>(G, R, side, a, blocks, st)
+                         : launch_phi_g<float, 2>(G, R, side, a, blocks, st);
+  return V == 2 ? launch_phi_g<double, 2>(G, R, side, a, blocks, st)
+                : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
 template <int G>
@@ -232,6 +235,20 @@ bool launch_sweep(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t
     case 64: return launch_sweep_r<64>(R, a, blocks, st);
   }
   return false;
+}
+
+// surfaces a numerical breakdown the kernels flagged (synchronises the stream)
+int check_flags(hpf_handle *h)
+{
+  uint32_t f = 0;
+  HIPCHK(h, hipMemcpyAsync(&f, h->flags, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (f & 1u) {
+    h->err = h->w32 ? "a softmax denominator underflowed to zero: the Elog spread is too wide for f32-stored W; use w_storage = 0"
+                    : "a softmax denominator underflowed to zero (Elog spread > ~700): the state is not a valid HPF state";
+    return HPF_ERR_STATE;
+  }
+  return HPF_OK;
 }
 
 int check_launch(hpf_handle *h, const char *what)
@@ -459,7 +476,7 @@ int prepare_derived(hpf_handle *h)
     if (!s->rows || !s->w_dirty) continue;
     s->w_dirty = false;
     const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
-    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
+    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W, (uint32_t)h->w32,
                        s->rows, h->ld, h->K, s->bias_col, s->junk_col);
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
@@ -485,10 +502,10 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
     PhiArgs a;
     a.segs = own.segs[ph]; a.nseg = own.nseg[ph]; a.idx = own.idx; a.val = own.val;
     a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
-    a.accumulate = ph;
+    a.accumulate = ph; a.flags = h->flags;
     if (a.nseg) {
       const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-      if (!launch_phi(h->phiG, h->phiR, h->phiV, side + 2 * (int)ph, a, blocks, h->stream)) {
+      if (!launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream)) {
         h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
       }
     }
@@ -508,7 +525,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   // remember what the rate was built from (export of *_rate.tsv)
   HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   SweepArgs a;
-  a.S = s.S; a.W = s.W;
+  a.S = s.S; a.W = s.W; a.w32 = h->w32;
   s.l_stale = true; s.es_stale = true;
   a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
   a.prior_elog = s.prior_elog; a.prior_elog_used = s.prior_elog_used;
@@ -598,7 +615,11 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.n_users_total == 0) h->cfg.n_users_total = cfg->n_users;
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
-  h->K = cfg->K; h->C = C; h->ld = (C + 1u) & ~1u;
+  h->w32 = cfg->w_storage == 1;
+  if (const char *e = getenv("HPF_W_STORAGE")) h->w32 = !strcmp(e, "f32") || !strcmp(e, "1");
+  if (cfg->w_storage > 1) { delete h; return HPF_ERR_INVALID; }
+  // 16-byte rows of W: 2 doubles or 4 floats
+  h->K = cfg->K; h->C = C; h->ld = h->w32 ? (C + 3u) & ~3u : (C + 1u) & ~1u;
 
   auto fail = [&](int rc) { hpf_destroy(h); return rc; };
   if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -612,25 +633,31 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
 
   // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
   {
-    // 16-byte loads (V=2) when they pad no worse than 8-byte ones (measured:
-    // C2 phi_user 4.36 ms vs 4.52 ms; the passes are fabric-bound either way)
+    // 16-byte loads when they pad no worse than 8-byte ones (measured: C2
+    // phi_user 4.36 ms vs 4.52 ms; the passes are fabric-bound either way).
+    // Elements per load: doubles 1|2, floats 2|4.
+    const int Vs = h->w32 ? 2 : 1, Vl = 2 * Vs;
     int g1 = 0, r1 = 0, g2 = 0, r2 = 0;
-    const bool ok1 = choose_cfg(h->ld, 1, &g1, &r1), ok2 = choose_cfg(h->ld, 2, &g2, &r2);
+    const bool ok1 = choose_cfg(h->ld, Vs, &g1, &r1), ok2 = choose_cfg(h->ld, Vl, &g2, &r2);
     if (!ok1 && !ok2) return fail(HPF_ERR_UNSUPPORTED);
-    const long w1 = ok1 ? (long)g1 * r1 - (long)h->ld : 1L << 30;
-    const long w2 = ok2 ? (long)g2 * r2 * 2 - (long)h->ld : 1L << 30;
-    if (w2 <= w1) { h->phiG = g2; h->phiR = r2; h->phiV = 2; }
-    else { h->phiG = g1; h->phiR = r1; h->phiV = 1; }
+    const long w1 = ok1 ? (long)g1 * r1 * Vs - (long)h->ld : 1L << 30;
+    const long w2 = ok2 ? (long)g2 * r2 * Vl - (long)h->ld : 1L << 30;
+    if (w2 <= w1) { h->phiG = g2; h->phiR = r2; h->phiV = Vl; }
+    else { h->phiG = g1; h->phiR = r1; h->phiV = Vs; }
+    if (h->w32) {
+      // f32 rows are half as long: measured at C2 (K=100) the passes want 256
+      // contiguous bytes per nonzero-group -- (G,R,V) = (16,2,4): 3.7 + 3.4 ms
+      // against 5.0 + 3.8 ms for (8,4,4) and 9.8 + 5.3 ms for the least-padding (4,7,4)
+      const int g = h->ld > 32 ? 16 : h->ld > 16 ? 8 : 4;
+      h->phiG = g; h->phiV = 4; h->phiR = (int)((h->ld + (uint32_t)(4 * g) - 1) / (uint32_t)(4 * g));
+    }
   }
   if (!choose_cfg(h->ld, 1, &h->swG, &h->swR)) return fail(HPF_ERR_UNSUPPORTED);
   if (const char *e = getenv("HPF_PHI_CFG")) {
     int g = 0, r = 0, v = 0;
-    if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (v == 1 || v == 2) && r >= 1 && r <= 8 &&
+    if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&
         (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && (uint32_t)(g * r * v) >= h->ld) {
       h->phiG = g; h->phiR = r; h->phiV = v;
-    } else if (sscanf(e, "v%d", &v) == 1 && (v == 1 || v == 2)) {
-      int g2, r2;
-      if (choose_cfg(h->ld, v, &g2, &r2)) { h->phiG = g2; h->phiR = r2; h->phiV = v; }
     }
   }
   if (const char *e = getenv("HPF_SWEEP_CFG")) {
@@ -660,7 +687,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (s == &h->u) { if ((rc = dalloc(h, &s->S, ne))) return fail(rc); }
     if ((rc = dalloc(h, &s->E, ne))) return fail(rc);
     if ((rc = dalloc(h, &s->L, ne))) return fail(rc);
-    if ((rc = dalloc(h, &s->W, ne))) return fail(rc);
+    { double *w = nullptr; if ((rc = dalloc(h, &w, ne))) return fail(rc); s->W = w; }   // sized for doubles; floats use half
     if ((rc = dalloc(h, &s->prior_E, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_used, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_rate, s->rows))) return fail(rc);
@@ -679,6 +706,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     double lf[256]; lf[0] = std::log(1.0); lf[1] = lf[0];
     for (uint32_t y = 2; y < 256; ++y) lf[y] = lf[y - 1] + std::log((double)y);
     if ((rc = dalloc(h, &h->logfact, 256))) return fail(rc);
+    if ((rc = dalloc(h, &h->flags, 1))) return fail(rc);
     if (hipMemcpyAsync(h->logfact, lf, sizeof lf, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
@@ -698,7 +726,7 @@ void hpf_destroy(hpf_handle *h)
   free_side(h->it, true);
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
-  dfree(h->logfact); dfree(h->rowptr_dev);
+  dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->flags);
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
     for (int e = 0; e < 7; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -949,6 +977,7 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
     return rc;
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
+  { int rc = check_flags(h); if (rc) return rc; }
   { int rc = kind == 3 ? refresh_elog(h, *s) : refresh_es(h, *s); if (rc) return rc; }
   const double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
   return copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
@@ -981,6 +1010,7 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     if (u[p] >= h->u.rows || i[p] >= h->it.rows) { h->err = "held-out index out of range"; return HPF_ERR_INVALID; }
   uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr;
   int rc = HPF_OK;
+  if ((rc = check_flags(h))) return rc;
   if ((rc = refresh_es(h, h->u)) || (rc = refresh_es(h, h->it))) return rc;
   std::vector<double> out(cnt);
   do {
@@ -1198,8 +1228,7 @@ int hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const u
 int hpf_synchronize(hpf_handle *h)
 {
   if (!h) return HPF_ERR_INVALID;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return HPF_OK;
+  return check_flags(h);
 }
 
 int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
@@ -1240,9 +1269,10 @@ int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item,
   // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
   const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
   const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
-  if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * 8 + n * Kp * 16;
-  if (phi_item) *phi_item = nnz * Kp * 8;
-  if (rows) *rows = (n + m) * Kp * 32 + 64 * (n + m);
+  const uint64_t se = h->w32 ? 4 : 8, sa = 8;        // bytes per stored W element / per accumulator
+  if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * se + n * Kp * (se + sa);
+  if (phi_item) *phi_item = nnz * Kp * se;
+  if (rows) *rows = (n + m) * Kp * (2 * sa + 2 * se) + 64 * (n + m);
   return HPF_OK;
 }
 

@@ -80,27 +80,28 @@ __device__ __forceinline__ double group_max(double v)
 // "batch" is 64/G nonzeros.  Row of W_other for the next batch is loaded
 // before the current batch is reduced (software prefetch).
 // ---------------------------------------------------------------------
-template <int V> struct vecd;
-template <> struct vecd<1> { double x[1]; };
-template <> struct __attribute__((aligned(16))) vecd<2> { double x[2]; };
+// V elements of type T moved by one 8- or 16-byte access
+template <typename T, int V>
+struct __attribute__((aligned((sizeof(T) * V > 16) ? 16 : sizeof(T) * V))) vecw { T x[V]; };
 
 struct PhiArgs {
   const Seg      *segs;
   uint32_t        nseg;
   const uint32_t *idx;      // other-side row of each nonzero
   const uint8_t  *val;      // rating (NULL: all ones)
-  const double   *W_own;    // [rows_own x ld]
-  const double   *W_oth;    // [rows_oth x ld]
+  const void     *W_own;    // [rows_own x ld] of WT (double, or float in the f32-storage mode)
+  const void     *W_oth;    // [rows_oth x ld] of WT
   double         *S_own;    // [rows_own x ld]  raw sums (prior added by sweep)
   double         *partial;  // [npartial x ld]
-  uint32_t        ld;       // row stride in doubles (even)
+  uint32_t       *flags;    // bit 0 set when a live nonzero saw sum_k e_k == 0 (underflow of W)
+  uint32_t        ld;       // row stride in elements (multiple of 16 bytes / sizeof(WT))
   uint32_t        accumulate;  // 1: direct rows add to S_own (second phase of a hot/cold split)
 };
 
+// WT: storage type of W.  Arithmetic and accumulators are fp64 either way.
 // SIDE only names the instantiation (0 = user-major pass over CSR, 1 =
-// item-major pass over CSC; +2 = the "cold" phase of a hot/cold split) so
-// that profilers report the passes apart.
-template <int G, int R, int V, int SIDE>
+// item-major pass over CSC) so that profilers report the passes apart.
+template <typename WT, int G, int R, int V, int SIDE>
 __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 {
   constexpr int NG = 64 / G;             // nonzeros per batch
@@ -110,27 +111,27 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t ld = a.ld;
+  const WT *W_own = (const WT *)a.W_own, *W_oth = (const WT *)a.W_oth;
 
   // column offsets of this lane and their validity (col < ld)
   bool cok[R];
 #pragma unroll
   for (int t = 0; t < R; ++t) cok[t] = (uint32_t)((g + G * t) * V) < ld;
+  bool underflow = false;
 
   for (uint32_t s = wave; s < a.nseg; s += nwaves) {
     const Seg sg = a.segs[s];
     const uint32_t len = sg.len;
     const int64_t start = sg.start;
 
-    vecd<V> own[R], acc[R];
-    const double *wo = a.W_own + (size_t)sg.row * ld + (size_t)g * V;
+    vecw<double, V> own[R], acc[R];
+    const WT *wo = W_own + (size_t)sg.row * ld + (size_t)g * V;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      if (cok[t]) own[t] = *reinterpret_cast<const vecd<V> *>(wo + (size_t)G * t * V);
-      else
+      vecw<WT, V> raw;
+      if (cok[t]) raw = *reinterpret_cast<const vecw<WT, V> *>(wo + (size_t)G * t * V);
 #pragma unroll
-        for (int v = 0; v < V; ++v) own[t].x[v] = 0.0;
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[t].x[v] = 0.0;
+      for (int v = 0; v < V; ++v) { own[t].x[v] = cok[t] ? (double)raw.x[v] : 0.0; acc[t].x[v] = 0.0; }
     }
 
     if (len > 0) {
@@ -144,16 +145,16 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
       // prefetch batch 0
       uint32_t in = __shfl(cur_i, q, 64);
       uint32_t yn = __shfl(cur_y, q, 64);
-      vecd<V> xn[R];
+      vecw<WT, V> xn[R];
       {
-        const double *p = a.W_oth + (size_t)in * ld + (size_t)g * V;
+        const WT *p = W_oth + (size_t)in * ld + (size_t)g * V;
 #pragma unroll
         for (int t = 0; t < R; ++t)
-          if (cok[t]) xn[t] = *reinterpret_cast<const vecd<V> *>(p + (size_t)G * t * V);
+          if (cok[t]) xn[t] = *reinterpret_cast<const vecw<WT, V> *>(p + (size_t)G * t * V);
       }
 
       for (uint32_t bb = 0; bb < nb; ++bb) {
-        vecd<V> x[R];
+        vecw<WT, V> x[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) x[t] = xn[t];
         const uint32_t y = yn;
@@ -171,10 +172,10 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
           const int src = (int)((b1 % G) * NG + q);
           in = __shfl(cur_i, src, 64);
           yn = __shfl(cur_y, src, 64);
-          const double *p = a.W_oth + (size_t)in * ld + (size_t)g * V;
+          const WT *p = W_oth + (size_t)in * ld + (size_t)g * V;
 #pragma unroll
           for (int t = 0; t < R; ++t)
-            if (cok[t]) xn[t] = *reinterpret_cast<const vecd<V> *>(p + (size_t)G * t * V);
+            if (cok[t]) xn[t] = *reinterpret_cast<const vecw<WT, V> *>(p + (size_t)G * t * V);
         }
 
         // ---- batch bb: e = W_own * W_oth ; phi = y * e / sum(e)
@@ -182,20 +183,21 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 #pragma unroll
         for (int t = 0; t < R; ++t)
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            double e = cok[t] ? own[t].x[v] * x[t].x[v] : 0.0;
-            x[t].x[v] = e;
-            ssum += e;
-          }
+          for (int v = 0; v < V; ++v) ssum += cok[t] ? own[t].x[v] * (double)x[t].x[v] : 0.0;
         ssum = group_sum<G>(ssum);
         // y == 0 (a rating that wrapped to 0 in the reference's uint8 store)
         // is not scaled: "if (y > 1) phi.scale(y)"  hgaprec.cc:1355-1356
         const double yy = (y > 1u) ? (double)y : 1.0;
-        const double scale = (act && ssum > 0.0) ? yy / ssum : 0.0;
+        const bool ok = ssum > 0.0;
+        underflow |= act && !ok;
+        const double scale = (act && ok) ? yy / ssum : 0.0;
+        // the product is formed again instead of kept: fewer live registers,
+        // same bits (own * x rounds identically both times)
 #pragma unroll
         for (int t = 0; t < R; ++t)
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc[t].x[v] = fma(x[t].x[v], scale, acc[t].x[v]);
+          for (int v = 0; v < V; ++v)
+            if (cok[t]) acc[t].x[v] = fma(own[t].x[v] * (double)x[t].x[v], scale, acc[t].x[v]);
       }
     }
 
@@ -214,9 +216,9 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
         acc[t].x[v] = r;
       }
       if (q == 0 && cok[t]) {
-        vecd<V> *pd = reinterpret_cast<vecd<V> *>(dst + (size_t)(g + G * t) * V);
+        vecw<double, V> *pd = reinterpret_cast<vecw<double, V> *>(dst + (size_t)(g + G * t) * V);
         if (a.accumulate && sg.pslot < 0) {      // S = (hot-phase sum) + (this phase's sum)
-          const vecd<V> old = *pd;
+          const vecw<double, V> old = *pd;
 #pragma unroll
           for (int v = 0; v < V; ++v) acc[t].x[v] = old.x[v] + acc[t].x[v];
         }
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
       }
     }
   }
+  if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
 // long rows: S[row] = sum over its segments' partials, in segment order.
@@ -319,7 +322,8 @@ __device__ __forceinline__ double digamma_pos(double x)
 // ---------------------------------------------------------------------
 struct SweepArgs {
   const double *S;          // [rows x ld] raw phi sums (read only)
-  double       *W;          // [rows x ld]
+  void         *W;          // [rows x ld] double, or float when w32
+  uint32_t      w32;
   double       *prior_E;    // [rows] E[xi] / E[eta]: in old, out new (hier)
   double       *prior_used; // [rows] value of prior_E used for this rate
   double       *prior_rate; // [rows] rate of the xi/eta Gamma after update
@@ -389,7 +393,10 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t c = g + G * t;
-      if (c < ld) a.W[base + c] = w[t] * inv;
+      if (c < ld) {
+        if (a.w32) ((float *)a.W)[base + c] = (float)(w[t] * inv);
+        else ((double *)a.W)[base + c] = w[t] * inv;
+      }
     }
     if (a.hier && g == 0) {
       // thetarate/betarate: gpbase.hh:877-889,912-925 via hgaprec.cc:1398-1414
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
 }
 
 // W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
-__global__ void derive_w_kernel(const double *L, double *W, uint32_t rows,
+__global__ void derive_w_kernel(const double *L, void *W, uint32_t w32, uint32_t rows,
                                 uint32_t ld, uint32_t K, int32_t bias_col,
                                 int32_t junk_col)
 {
@@ -521,7 +528,9 @@ __global__ void derive_w_kernel(const double *L, double *W, uint32_t rows,
     m = group_max<64>(m);
     for (uint32_t c = lane; c < ld; c += 64) {
       const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
-      W[(size_t)row * ld + c] = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
+      const double wv = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
+      if (w32) ((float *)W)[(size_t)row * ld + c] = (float)wv;
+      else ((double *)W)[(size_t)row * ld + c] = wv;
     }
   }
 }

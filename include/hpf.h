@@ -82,7 +82,11 @@ typedef struct {
   int32_t  device;         /* HIP device ordinal                             */
   uint32_t n_ranks;        /* 1 => hpf_iterate() needs no exchange           */
   uint32_t rank;
-  uint32_t reserved0;
+  uint32_t w_storage;      /* 0: W = exp(Elog - rowmax) stored fp64 (default).   */
+                           /* 1: EXPERIMENTAL, stored fp32 (gathers halve, 1.4x   */
+                           /*    faster at C2) -- measured to drift out of the    */
+                           /*    1e-4 parity contract after ~30 iterations; see   */
+                           /*    DESIGN.md.  Never selected implicitly.           */
   void    *stream;         /* hipStream_t to run on, NULL => own stream      */
   double   s_prior;        /* 0.3 (hgaprec.cc:13-20 hard-codes both)         */
   double   r_prior;        /* 0.3                                            */

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-def _run_pair(orc, n, m, K, nnz, hier, bias, binary, iters, seed, prob_kw=None, val_mode="ratings"):
+def _run_pair(orc, n, m, K, nnz, hier, bias, binary, iters, seed, prob_kw=None, val_mode="ratings",
+              w_storage=0):
     from hgaprec_amd.capi import Hpf
     rowptr, col, val = make_problem(n, m, nnz, seed, **(prob_kw or {}))
     if val_mode == "wrap0":            # ratings that wrapped to 0 in the uint8 store
@@ -28,7 +29,7 @@ def _run_pair(orc, n, m, K, nnz, hier, bias, binary, iters, seed, prob_kw=None, 
     M = orc.Model(n, m, K, hier, bias, binary)
     M.set_csr(rowptr, col, val_o)
     M.initialize(seed)
-    D = Hpf(n, m, K, hier=hier, bias=bias, binary=binary)
+    D = Hpf(n, m, K, hier=hier, bias=bias, binary=binary, w_storage=w_storage)
     D.upload_csr(rowptr, col, val_d)
     copy_state(M, D, hier, bias)
     return M, D
@@ -297,3 +298,60 @@ def test_single_user_and_no_nonzeros(orc):
         D.iterate(2)
         for w in compare_states(True, False):
             assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+
+
+@pytest.mark.parametrize("K,hier,bias", [(5, True, False), (21, True, True), (100, True, False), (50, False, True)])
+def test_f32_stored_w_experimental_mode(orc, K, hier, bias):
+    """EXPERIMENTAL storage mode (hpf_config.w_storage = 1; never the default):
+    W = exp(Elog - rowmax) kept in fp32, arithmetic and accumulators fp64.  Each
+    W carries a 2^-24 relative rounding which the CAVI map amplifies: measured
+    (tools/w32_error_growth.py) 3e-7 after 5 sweeps, 2e-5 after 20, 1e-3 after
+    60, up to 1e-1 after 300 -- it leaves the 1e-4 contract after ~30 sweeps,
+    which is why the product stores W in fp64 (drift 1e-9 at 300 sweeps).
+    The mode itself must work, be deterministic and be accurate for short runs."""
+    outs = []
+    for rep in range(2):
+        M, D = _run_pair(orc, 400, 300, K, 12000, hier, bias, False, 5, seed=5, w_storage=1)
+        D.iterate(5)
+        outs.append((D.get_state("THETA_E"), D.get_state("BETA_E")))
+    M.iterate(5)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    et, eb = rel_err(outs[0][0], M.state("THETA_E")), rel_err(outs[0][1], M.state("BETA_E"))
+    assert et < 2e-6 and eb < 2e-6, (et, eb)
+    assert et > 1e-12                                   # it really is a different storage precision
+
+
+def test_fp64_drift_stays_tiny_over_many_sweeps(orc):
+    # the default path against the oracle after 150 sweeps (contract: 1e-4)
+    M, D = _run_pair(orc, 400, 300, 50, 12000, True, True, False, 150, seed=5)
+    M.iterate(150)
+    D.iterate(150)
+    for w in ("THETA_E", "BETA_E", "XI_E", "ETA_E", "UBIAS_E", "IBIAS_E"):
+        assert rel_err(D.get_state(w), M.state(w)) < 1e-8, w
+
+
+def test_softmax_underflow_is_reported_not_hidden(orc):
+    """rows whose Elog spread exceeds what the stored W can represent make every
+    product of a nonzero vanish; the device raises a flag and the next
+    synchronising call fails instead of silently dropping the nonzero"""
+    from hgaprec_amd.capi import Hpf, HpfError
+    n, m, K = 30, 20, 2
+    rowptr, col, val = make_problem(n, m, 200, 3)
+    M = orc.Model(n, m, K, True, False, False)
+    M.set_csr(rowptr, col, val)
+    M.initialize(1)
+    lt = np.tile(np.array([0.0, -150.0]), (n, 1))
+    lb = np.tile(np.array([-150.0, 0.0]), (m, 1))
+    for ws, should_fail in ((1, True), (0, False)):     # e^-150 is 0 in fp32, fine in fp64
+        D = Hpf(n, m, K, w_storage=ws)
+        D.upload_csr(rowptr, col, val)
+        copy_state(M, D, True, False)
+        D.set_state("THETA_ELOG", lt)
+        D.set_state("BETA_ELOG", lb)
+        D.iterate(1)
+        if should_fail:
+            with pytest.raises(HpfError, match="underflow"):
+                D.synchronize()
+        else:
+            D.synchronize()
+            assert np.all(np.isfinite(D.get_state("THETA_E")))
