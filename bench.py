@@ -80,6 +80,13 @@ def main():
                     help="debug: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
+    # RCCL prints a version banner through C stdio on stdout (flushed at process
+    # exit when stdout is a pipe).  Keep the real stdout for the ONE JSON line:
+    # everything else that lands on fd 1 is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from hgaprec_amd import synth
@@ -97,8 +104,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HPF_BENCH_FORCE_DIST=1: take the N>1 code path (process group, bound exchange
+    # tensor, all_reduce per step) even with one rank -- lets a 1-GPU box exercise
+    # the RCCL calls and the stream ordering
+    force_dist = os.environ.get("HPF_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -129,10 +144,10 @@ def main():
     log(f"[rank {rank}] generated {n_loc} x {m}, nnz={nnz_loc} in {time.perf_counter() - t0:.1f}s")
 
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
-            device=local_rank, stream=stream.cuda_stream, n_ranks=world, rank=rank,
-            n_users_total=n_loc * world, w_storage=1 if args.w32 else 0)
+            device=local_rank, stream=stream.cuda_stream, n_ranks=2 if (force_dist and world == 1) else world,
+            rank=rank, n_users_total=n_loc * world, w_storage=1 if args.w32 else 0)
     xbuf = None
-    if world > 1:
+    if use_dist:
         xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
         D.bind_exchange_buffer(xbuf.data_ptr(), xbuf.numel())
     t0 = time.perf_counter()
@@ -160,7 +175,7 @@ def main():
     log(f"[rank {rank}] upload {t_upload:.1f}s, state {time.perf_counter() - t0:.1f}s")
 
     def step():
-        if world == 1:
+        if not use_dist:
             D.iterate(1)
         else:
             D.iterate_local()
@@ -168,7 +183,7 @@ def main():
             D.iterate_global()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +195,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -191,7 +206,7 @@ def main():
         nnz_total = nnz_loc
 
     replica_check = None
-    if world > 1:
+    if use_dist:
         # every rank must hold bit-identical item-side state after the same
         # all-reduced sums: a cheap end-of-run guard against an ordering race
         be = D.get_state("BETA_E")
@@ -245,9 +260,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, rowptr, col, val)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     D.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
