@@ -31,6 +31,10 @@ struct Env {
   int device = 0; bool device_set = false;
   int ngpus = 1;
   std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)
+  // extension (the reference has no training resume: its -load is inert,
+  // main.cc:137-140): -checkpoint N writes <outdir>/checkpoint.r<rank>of<world>.bin
+  // every N iterations, -resume continues from it
+  uint32_t checkpoint_every = 0; bool resume = false;
 
   std::string prefix;          // output directory (Env::prefix)
   FILE *plogf = nullptr;       // param.txt

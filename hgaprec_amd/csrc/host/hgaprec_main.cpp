@@ -76,7 +76,7 @@ struct Driver {
       const char *names[] = {"/heldout.txt", "/validation.txt", "/test.txt", "/logl.txt",
                              "/precision.txt", "/ndcg.txt", "/rmse.txt"};
       for (const char *nm : names) {
-        FILE *f = fopen(env.file_str(nm).c_str(), "w");
+        FILE *f = fopen(env.file_str(nm).c_str(), env.resume ? "a" : "w");
         if (!f) { printf("cannot open heldout file:%s\n", strerror(errno)); exit(-1); }
         if (!strcmp(nm, "/validation.txt")) vf = f;
         else if (!strcmp(nm, "/test.txt")) tf = f;
@@ -440,11 +440,78 @@ struct Driver {
     exit(code);
   }
 
+  // ---- checkpoint / resume (extension) -----------------
+  // Everything the loop needs to go on: iteration, stop-rule state, the
+  // MT19937 state, the sampled users and every Gamma array of this rank.
+  std::string checkpoint_path() const {
+    return env.file_str("/checkpoint.r" + std::to_string(comm.rank) + "of" + std::to_string(comm.world) + ".bin");
+  }
+  std::vector<hpf_state> checkpoint_states() const {
+    std::vector<hpf_state> v = {HPF_THETA_SHAPE, HPF_THETA_RATE, HPF_THETA_E, HPF_THETA_ELOG,
+                                HPF_BETA_SHAPE, HPF_BETA_RATE, HPF_BETA_E, HPF_BETA_ELOG};
+    if (env.hier) for (int w = HPF_XI_SHAPE; w <= HPF_ETA_ELOG; ++w) v.push_back((hpf_state)w);
+    if (env.bias) for (hpf_state w : {HPF_UBIAS_SHAPE, HPF_UBIAS_E, HPF_UBIAS_ELOG, HPF_IBIAS_SHAPE, HPF_IBIAS_E, HPF_IBIAS_ELOG}) v.push_back(w);
+    return v;
+  }
+  size_t state_count(hpf_state w) const {
+    const int obj = w / 4, kind = w % 4;
+    const size_t rows = (obj == 0 || obj == 2 || obj == 4) ? hi - lo : m;
+    if (obj <= 1) return (kind == 1 && !env.hier) ? k : rows * k;
+    return rows;
+  }
+  void write_checkpoint() {
+    const std::string path = checkpoint_path(), tmp = path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) { fprintf(stderr, "warning: cannot write %s\n", tmp.c_str()); return; }
+    const uint32_t head[13] = {1u, (uint32_t)comm.world, (uint32_t)comm.rank, n, lo, hi, m, k,
+                               (uint32_t)env.hier, (uint32_t)env.bias, (uint32_t)env.binary_data, iter + 1, stop.nh};
+    fwrite("HPFCKPT1", 1, 8, f); fwrite(head, 4, 13, f); fwrite(&stop.prev_h, 8, 1, f);
+    fwrite(rng.mt, 4, 624, f); const int32_t mti = rng.mti; fwrite(&mti, 4, 1, f);
+    const uint32_t ns = (uint32_t)sampled.size(); fwrite(&ns, 4, 1, f); fwrite(sampled.data(), 4, ns, f);
+    std::vector<double> buf;
+    for (hpf_state w : checkpoint_states()) {
+      const uint64_t cnt = state_count(w); const uint32_t id = (uint32_t)w;
+      buf.resize(cnt);
+      int rc = hpf_get_state(h, w, buf.data(), cnt);
+      if (rc) die("hpf_get_state (checkpoint)", rc);
+      fwrite(&id, 4, 1, f); fwrite(&cnt, 8, 1, f); fwrite(buf.data(), 8, cnt, f);
+    }
+    const uint32_t end = 0xffffffffu; fwrite(&end, 4, 1, f);
+    fclose(f);
+    rename(tmp.c_str(), path.c_str());
+  }
+  void read_checkpoint() {
+    const std::string path = checkpoint_path();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "error: [rank %d] -resume: cannot open %s\n", comm.rank, path.c_str()); exit(-1); }
+    auto need = [&](bool ok) { if (!ok) { fprintf(stderr, "error: [rank %d] %s is not a checkpoint of this run\n", comm.rank, path.c_str()); exit(-1); } };
+    char magic[8]; uint32_t head[13];
+    need(fread(magic, 1, 8, f) == 8 && !memcmp(magic, "HPFCKPT1", 8) && fread(head, 4, 13, f) == 13);
+    need(head[0] == 1 && head[1] == (uint32_t)comm.world && head[2] == (uint32_t)comm.rank && head[3] == n &&
+         head[4] == lo && head[5] == hi && head[6] == m && head[7] == k && head[8] == (uint32_t)env.hier &&
+         head[9] == (uint32_t)env.bias && head[10] == (uint32_t)env.binary_data);
+    iter = head[11]; stop.nh = head[12];
+    need(fread(&stop.prev_h, 8, 1, f) == 1 && fread(rng.mt, 4, 624, f) == 624);
+    int32_t mti; need(fread(&mti, 4, 1, f) == 1); rng.mti = mti;
+    uint32_t ns; need(fread(&ns, 4, 1, f) == 1); sampled.resize(ns); need(fread(sampled.data(), 4, ns, f) == ns);
+    std::vector<double> buf;
+    while (true) {
+      uint32_t id; need(fread(&id, 4, 1, f) == 1);
+      if (id == 0xffffffffu) break;
+      uint64_t cnt; need(fread(&cnt, 8, 1, f) == 1 && id < HPF_NUM_STATE && cnt == state_count((hpf_state)id));
+      buf.resize(cnt); need(fread(buf.data(), 8, cnt, f) == cnt);
+      int rc = hpf_set_state(h, (hpf_state)id, buf.data(), cnt);
+      if (rc) die("hpf_set_state (resume)", rc);
+    }
+    fclose(f);
+    if (root()) env.lerr("resumed from %s at iteration %d", path.c_str(), iter);
+  }
+
   // the three batch loops share one shape; only -hier honours max_iterations
   // (hgaprec.cc:1337-1339; vb() and vb_bias() run until the stop rule fires)
   void run() {
     if (!env.hier && root()) env.lerr(env.bias ? "running vb_bias()" : "running vb()");
-    initialize();
+    if (env.resume) read_checkpoint(); else initialize();
     while (1) {
       if (env.hier && iter > env.max_iterations) finish(0);
       iterate();
@@ -469,6 +536,7 @@ struct Driver {
         if (root()) env.lerr("Saving state at iteration %d duration %d secs", iter, duration());
         do_on_stop();
       }
+      if (env.checkpoint_every && iter > 0 && iter % env.checkpoint_every == 0) write_checkpoint();
       iter++;
     }
   }

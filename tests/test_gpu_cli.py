@@ -191,3 +191,38 @@ def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
             ib, vb = read_tsv(ref / f"{nm}{suf}.tsv")
             assert np.array_equal(ia, ib), nm + suf
             assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf
+
+
+def test_checkpoint_and_resume(tmp_path):
+    """-checkpoint N / -resume (an extension: the reference cannot resume).  A
+    run stopped after 6 iterations and resumed to 14 must end where the
+    uninterrupted run ends (the restart re-derives W from Elog: last-ulp level
+    differences only) and append to the same report files."""
+    n, m, K = 300, 200, 6
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    base = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "3", "-rfreq", "2", "-hier", "-bias"]
+    a, b = tmp_path / "straight", tmp_path / "resumed"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "14"], cwd=a, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "6", "-checkpoint", "6"], cwd=b, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outb = [p for p in b.iterdir() if p.is_dir()][0]
+    assert (outb / "checkpoint.r0of1.bin").exists()
+    assert len(series(outb / "validation.txt")) == 4                      # iterations 0, 2, 4, 6
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "14", "-resume"], cwd=b, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outa = [p for p in a.iterdir() if p.is_dir()][0]
+    sa, sb = series(outa / "validation.txt"), series(outb / "validation.txt")
+    assert [x[0] for x in sa] == [x[0] for x in sb] == list(range(0, 15, 2))
+    assert max(abs(x[1] - y[1]) for x, y in zip(sa, sb)) < 1e-9
+    assert (outa / "precision.txt").read_text() == (outb / "precision.txt").read_text()   # same RNG stream
+    for nm in ("htheta", "hbeta", "thetarate", "betarate", "thetabias", "betabias"):
+        for suf in ("", "_shape", "_rate"):
+            _, va = read_tsv(outa / f"{nm}{suf}.tsv")
+            _, vb = read_tsv(outb / f"{nm}{suf}.tsv")
+            assert np.max(np.abs(va - vb)) <= 1.1e-8, nm + suf                  # at most a %.8f rounding flip
+    # a checkpoint of another configuration is refused
+    r = subprocess.run([str(EXE)] + base[:-1] + ["-max-iterations", "14", "-resume"], cwd=b, capture_output=True, text=True)
+    assert r.returncode != 0
