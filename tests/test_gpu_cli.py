@@ -226,3 +226,49 @@ def test_checkpoint_and_resume(tmp_path):
     # a checkpoint of another configuration is refused
     r = subprocess.run([str(EXE)] + base[:-1] + ["-max-iterations", "14", "-resume"], cwd=b, capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
+    """BASELINE config C1: the MovieLens-1M stand-in (the real example/ tarball is
+    not in the reference mount): 6040 x 3681, ~1.0M ratings split 80/1/19,
+    K=20, -hier, through the TSV path, CLI vs the oracle's end-to-end run."""
+    import torch
+    from hgaprec_amd import synth
+    cfg = synth.CONFIGS["C1"]
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    rowptr, col, val = synth.generate(n, m, 1_000_209, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"],
+                                      device="cuda" if torch.cuda.is_available() else "cpu")
+    rng = np.random.default_rng(cfg["seed"])
+    uid = rng.permutation(10 * n)[:n] + 1
+    iid = rng.permutation(10 * m)[:m] + 1
+    u = np.repeat(np.arange(n), np.diff(rowptr))
+    split = rng.random(u.size)
+    order = rng.permutation(u.size)
+    data = tmp_path / "ml"
+    data.mkdir()
+    lines = np.char.add(np.char.add(np.char.add(uid[u].astype(str), "\t"), np.char.add(iid[col].astype(str), "\t")),
+                        np.char.add(val.astype(str), "\n"))
+    for name, sel in (("train.tsv", split[order] >= 0.20), ("validation.tsv", split[order] < 0.01),
+                      ("test.tsv", (split[order] >= 0.01) & (split[order] < 0.20))):
+        (data / name).write_text("".join(lines[order][sel].tolist()))
+    args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-hier", "-rfreq", "5", "-max-iterations", "10"]
+    r = subprocess.run([str(EXE)] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = tmp_path / f"n{n}-m{m}-k{K}-batch-hier-vb"          # -dir is an absolute path: no 2-letter tag
+    assert out.is_dir()
+    ref = tmp_path / "oracle_out"
+    ref.mkdir()
+    orc.run(data, ref, n, m, K, hier=True, rfreq=5, max_iterations=10, seed=0)
+    for f in ("byusers.tsv", "byitems.tsv", "precision.txt"):
+        assert (out / f).read_text() == (ref / f).read_text(), f
+    for f in ("validation.txt", "test.txt"):
+        a, b = series(out / f), series(ref / f)
+        assert [x[0] for x in a] == [x[0] for x in b] == [0, 5, 10] and [x[2] for x in a] == [x[2] for x in b]
+        assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    for nm in ("hbeta", "htheta", "betarate", "thetarate"):
+        for suf in ("", "_shape", "_rate"):
+            ia, va = read_tsv(out / f"{nm}{suf}.tsv")
+            ib, vb = read_tsv(ref / f"{nm}{suf}.tsv")
+            assert np.array_equal(ia, ib), nm + suf
+            assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf
+            assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf
