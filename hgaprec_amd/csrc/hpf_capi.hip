@@ -158,14 +158,14 @@ void free_side(Side &s, bool S_external)
 }
 
 // pick (G,R[,V]) with G*R*V >= ld, R <= 8, least padding, then fewest registers
-bool choose_cfg(uint32_t ld, int V, int *G, int *R)
+bool choose_cfg(uint32_t ld, int V, int *G, int *R, int rmax64 = 8)
 {
   int bestG = 0, bestR = 0; long bestw = -1;
   const int Gs[5] = {4, 8, 16, 32, 64};
   for (int gi = 0; gi < 5; ++gi) {
     const int g = Gs[gi];
     const int r = (int)((ld + (uint32_t)(g * V) - 1) / (uint32_t)(g * V));
-    if (r < 1 || r > 8) continue;
+    if (r < 1 || r > (g == 64 ? rmax64 : 8)) continue;
     const long w = (long)g * r * V - (long)ld;
     if (bestw < 0 || w < bestw || (w == bestw && r < bestR)) { bestw = w; bestG = g; bestR = r; }
   }
@@ -222,6 +222,7 @@ bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
 #define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR>), dim3(blocks), dim3(256), 0, st, a); return true;
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
+  if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
@@ -648,11 +649,11 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       // f32 rows are half as long: measured at C2 (K=100) the passes want 256
       // contiguous bytes per nonzero-group -- (G,R,V) = (16,2,4): 3.7 + 3.4 ms
       // against 5.0 + 3.8 ms for (8,4,4) and 9.8 + 5.3 ms for the least-padding (4,7,4)
-      const int g = h->ld > 32 ? 16 : h->ld > 16 ? 8 : 4;
+      const int g = h->ld > 512 ? 32 : h->ld > 32 ? 16 : h->ld > 16 ? 8 : 4;
       h->phiG = g; h->phiV = 4; h->phiR = (int)((h->ld + (uint32_t)(4 * g) - 1) / (uint32_t)(4 * g));
     }
   }
-  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR)) return fail(HPF_ERR_UNSUPPORTED);
+  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR, 16)) return fail(HPF_ERR_UNSUPPORTED);
   if (const char *e = getenv("HPF_PHI_CFG")) {
     int g = 0, r = 0, v = 0;
     if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&

@@ -46,7 +46,7 @@ typedef enum {
   HPF_ERR_STATE = -6         /* state not initialised (no CSR / no E, Elog)   */
 } hpf_status;
 
-#define HPF_MAX_COLUMNS 512
+#define HPF_MAX_COLUMNS 1024
 
 /* Gamma objects of the model (HGAPRec members, hgaprec.hh:94-112) x the four
  * per-object arrays of gpbase.hh (shape_curr, rate_curr, expected_v,

@@ -252,7 +252,8 @@ def test_library_rccl_allreduce_world1(orc):
     assert np.array_equal(D.exchange_read(), before * 2.0)
 
 
-@pytest.mark.parametrize("K,bias", [(1, False), (1, True), (2, False), (333, False), (512, False), (510, True)])
+@pytest.mark.parametrize("K,bias", [(1, False), (1, True), (2, False), (333, False), (512, False), (510, True),
+                                    (700, False), (1024, False), (1022, True)])
 def test_extreme_factor_counts(orc, K, bias):
     n, m = 40, 30
     M, D = _run_pair(orc, n, m, K, 400, True, bias, False, 2, seed=K)
@@ -265,9 +266,9 @@ def test_extreme_factor_counts(orc, K, bias):
 def test_unsupported_and_invalid_inputs_fail_loudly():
     from hgaprec_amd.capi import Hpf, HpfError
     with pytest.raises(HpfError):
-        Hpf(10, 10, 513)                         # K > HPF_MAX_COLUMNS
+        Hpf(10, 10, 1025)                        # K > HPF_MAX_COLUMNS
     with pytest.raises(HpfError):
-        Hpf(10, 10, 511, bias=True)              # K + 2 > HPF_MAX_COLUMNS
+        Hpf(10, 10, 1023, bias=True)             # K + 2 > HPF_MAX_COLUMNS
     D = Hpf(4, 3, 2)
     with pytest.raises(HpfError):
         D.iterate(1)                             # no CSR, no state
