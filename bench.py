@@ -150,6 +150,8 @@ def main():
     if use_dist:
         xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
         D.bind_exchange_buffer(xbuf.data_ptr(), xbuf.numel())
+        ld_x = xbuf.numel() // (m + 1)                        # [m x ld | ld]
+        x_items, x_tail = xbuf[: m * ld_x], xbuf[m * ld_x:]
     t0 = time.perf_counter()
     D.upload_csr(rowptr, col, val)
     t_upload = time.perf_counter() - t0
@@ -178,8 +180,14 @@ def main():
         if not use_dist:
             D.iterate(1)
         else:
-            D.iterate_local()
-            dist.all_reduce(xbuf)          # RCCL sum over xGMI, ordered on this stream
+            # the item shape sums (m*ld doubles) are final after the phi passes:
+            # their all-reduce runs on RCCL's stream while the user sweep runs
+            # on ours; sum_u E[theta] (ld doubles) follows in a second, tiny one
+            D.iterate_local_phi()
+            w = dist.all_reduce(x_items, async_op=True)
+            D.iterate_local_sweep()
+            dist.all_reduce(x_tail)
+            w.wait()
             D.iterate_global()
 
     def fence():

@@ -31,7 +31,7 @@ STATE = {n: i for i, n in enumerate(STATE_NAMES)}
 EXPORTS = [
     "hpf_abi_version", "hpf_strerror", "hpf_last_error", "hpf_create", "hpf_destroy",
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
-    "hpf_iterate_local", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
+    "hpf_iterate_local", "hpf_iterate_local_phi", "hpf_iterate_local_sweep", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
     "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
@@ -91,6 +91,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_iterate.argtypes = [vp, C.c_int]
     lib.hpf_iterate_local.argtypes = [vp]
     lib.hpf_iterate_global.argtypes = [vp]
+    lib.hpf_iterate_local_phi.argtypes = [vp]
+    lib.hpf_iterate_local_sweep.argtypes = [vp]
     lib.hpf_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.hpf_bind_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.hpf_heldout_ll.argtypes = [vp, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t, dp,
@@ -211,6 +213,12 @@ class Hpf:
 
     def iterate_local(self):
         self._check(self.lib.hpf_iterate_local(self._h))
+
+    def iterate_local_phi(self):
+        self._check(self.lib.hpf_iterate_local_phi(self._h))
+
+    def iterate_local_sweep(self):
+        self._check(self.lib.hpf_iterate_local_sweep(self._h))
 
     def iterate_global(self):
         self._check(self.lib.hpf_iterate_global(self._h))

@@ -543,7 +543,8 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   return check_launch(h, "row sweep");
 }
 
-int iterate_local(hpf_handle *h)
+// first half of the rank-local work: both phi passes (step A)
+int iterate_local_phi(hpf_handle *h)
 {
   int rc;
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
@@ -556,10 +557,25 @@ int iterate_local(hpf_handle *h)
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if ((rc = run_phi(h, h->it, h->u, h->ev[3]))) return rc;   // step A, beta shape sums
   HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-  // steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits d = sum_u E[theta]
+  return HPF_OK;
+}
+
+// second half: steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits
+// d = sum_u E[theta] into the tail of the exchange buffer.  Does not touch the
+// item part of the exchange buffer, so its all-reduce may already be running.
+int iterate_local_sweep(hpf_handle *h)
+{
+  int rc;
   if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
   HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
   return HPF_OK;
+}
+
+int iterate_local(hpf_handle *h)
+{
+  int rc;
+  if ((rc = iterate_local_phi(h))) return rc;
+  return iterate_local_sweep(h);
 }
 
 int iterate_global(hpf_handle *h)
@@ -997,6 +1013,8 @@ int hpf_iterate(hpf_handle *h, int n_iters)
 }
 
 int hpf_iterate_local(hpf_handle *h) { return h ? iterate_local(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_phi(hpf_handle *h) { return h ? iterate_local_phi(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_sweep(hpf_handle *h) { return h ? iterate_local_sweep(h) : HPF_ERR_INVALID; }
 int hpf_iterate_global(hpf_handle *h) { return h ? iterate_global(h) : HPF_ERR_INVALID; }
 
 int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const int32_t *y,

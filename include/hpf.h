@@ -141,6 +141,13 @@ int  hpf_iterate(hpf_handle *h, int n_iters);
 /* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,
  * E) and the local partial sums ... */
 int  hpf_iterate_local(hpf_handle *h);
+/* hpf_iterate_local in two halves, for callers that overlap communication:
+ * _phi runs the two phi passes -- after it the first n_items*ld doubles of the
+ * exchange buffer (the item shape sums) are final and their all-reduce may
+ * start; _sweep runs the user sweep, which only writes the last ld doubles
+ * (sum_u E[theta_u,:]), reduced in a second, tiny all-reduce. */
+int  hpf_iterate_local_phi(hpf_handle *h);
+int  hpf_iterate_local_sweep(hpf_handle *h);
 /* ... the caller sum-all-reduces this device buffer of `count` doubles in
  * place (RCCL ncclAllReduce(ncclDouble, ncclSum) / torch.distributed) on the
  * handle's stream ... */
