@@ -95,6 +95,14 @@ int hg_save_matrix(const char *path, const double *a, uint32_t rows, uint32_t co
 int hg_save_vector(const char *path, const double *a, uint32_t rows, const uint32_t *ids, uint32_t nids)
 { return save_vector(path, a, rows, ids, nids); }
 
+// user ranges of a multi-process run: out[2*r], out[2*r+1] = [lo, hi) of rank r
+void hg_partition_users(const int64_t *rowptr, uint32_t n, int world, uint32_t *out)
+{
+  std::vector<int64_t> rp(rowptr, rowptr + n + 1);
+  auto parts = partition_users(rp, world);
+  for (int r = 0; r < world; ++r) { out[2 * r] = parts[r].first; out[2 * r + 1] = parts[r].second; }
+}
+
 // format_fixed8 over an array; out receives the strings separated by '\n'
 size_t hg_format_fixed8(const double *v, size_t n, char *out)
 {

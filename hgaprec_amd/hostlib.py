@@ -52,6 +52,8 @@ def lib():
     L.hg_save_vector.argtypes = [C.c_char_p, dp, C.c_uint32, u32p, C.c_uint32]
     L.hg_format_fixed8.argtypes = [dp, C.c_size_t, C.c_char_p]
     L.hg_format_fixed8.restype = C.c_size_t
+    L.hg_partition_users.argtypes = [C.POINTER(C.c_int64), C.c_uint32, C.c_int, u32p]
+    L.hg_partition_users.restype = None
     L.hg_stop_rule.argtypes = [u32p, dp, C.c_uint32, C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -183,6 +185,15 @@ def format_fixed8(values):
     buf = C.create_string_buffer(a.size * 420 + 16)
     n = lib().hg_format_fixed8(a.ctypes.data_as(C.POINTER(C.c_double)), a.size, buf)
     return buf.raw[:n].decode().split("\n")[:-1]
+
+
+def partition_users(rowptr, world):
+    """the C++ host's user sharding (same rule as hgaprec_amd.dist.partition_users)"""
+    rp = np.ascontiguousarray(rowptr, np.int64)
+    out = np.empty(2 * world, np.uint32)
+    lib().hg_partition_users(rp.ctypes.data_as(C.POINTER(C.c_int64)), rp.size - 1, world,
+                             out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world)]
 
 
 def stop_rule(iters, series):

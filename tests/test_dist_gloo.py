@@ -204,3 +204,13 @@ def test_partition_degenerate():
     rowptr = np.array([0, 5, 5, 5, 5], np.int64)          # all nnz in the first user
     parts = hd.partition_users(rowptr, 4)
     assert parts == [(0, 1), (1, 2), (2, 3), (3, 4)]
+
+
+def test_cpp_and_python_partition_agree():
+    from hgaprec_amd import hostlib
+    for seed, alpha in ((1, 0.5), (2, 0.9), (3, 1.3)):
+        rowptr, _, _ = make_problem(1500, 200, 30000, seed, alpha_u=alpha)
+        for world in (1, 2, 3, 8):
+            assert hostlib.partition_users(rowptr, world) == hd.partition_users(rowptr, world)
+    rowptr = np.array([0, 5, 5, 5, 5], np.int64)
+    assert hostlib.partition_users(rowptr, 4) == hd.partition_users(rowptr, 4)
