@@ -50,11 +50,19 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
     M.iterate(1)
     dt = time.perf_counter() - t0
     log(f"[cpu_baseline] slice users={s} nnz={nz} init={t_init:.1f}s iterate={dt:.2f}s")
+    # context only (not the contract's cpu_baseline): the same restatement with
+    # step A spread over every host core (OpenMP over users, atomics on item rows)
+    t0 = time.perf_counter()
+    M.iterate_all_cores()
+    dt_all = time.perf_counter() - t0
+    log(f"[cpu_baseline] all cores ({orc.omp_threads()} threads): iterate={dt_all:.2f}s")
     return {
         "value": nz / dt, "unit": "rating-nonzeros/s", "cores": 1, "kind": "port",
         "sample": f"1 CAVI iteration of oracle/liborc.so (single thread) on the first {s} users "
                   f"({nz} nonzeros) of the same matrix, all {cfg['m']} items, K={cfg['K']}",
         "seconds": dt,
+        "all_cores": {"value": nz / dt_all, "cores": orc.omp_threads(), "seconds": dt_all,
+                      "note": "same slice, step A under OpenMP (atomics on item rows), row sweeps serial"},
     }
 
 

@@ -526,6 +526,7 @@ struct orc_model {
   gp ubias, ibias;         /* thetabias / betabias                   */
   orc_rng rng;
   double *phi, *tmpK, *tmpN;
+  int skip_step_a;
 };
 
 orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
@@ -589,6 +590,7 @@ void orc_model_initialize(orc_model *M, double seed)
    get_phi hgaprec.cc:206-239 */
 static void sweep_nonzeros(orc_model *M)
 {
+  if (M->skip_step_a) return;           /* orc_model_iterate_all_cores already did it */
   const uint32_t K = M->K, x = M->bias ? K + 2 : K;
   double *phi = M->phi;
   for (uint32_t n = 0; n < M->n; ++n) {
@@ -676,6 +678,65 @@ static void iterate_flat(orc_model *M)  /* vb(): hgaprec.cc:927-956 ; vb_bias():
   for (uint32_t k = 0; k < K; ++k) M->beta.rnext[k] += M->tmpK[k];
   gp_swap(&M->beta); gp_compute_expectations(&M->beta);
   if (M->bias) bias_sweeps(M);
+}
+
+/* ---- all-cores variant of step A: OpenMP over users,
+   atomic adds on the shared item rows.  Used only for the extra
+   "cpu_baseline_all_cores" figure of bench.py; results differ from the serial
+   sweep by summation order only. ---- */
+#ifdef _OPENMP
+#include <omp.h>
+static void sweep_nonzeros_omp(orc_model *M)
+{
+  const uint32_t K = M->K, x = M->bias ? K + 2 : K;
+#pragma omp parallel
+  {
+    double *phi = (double *)malloc(sizeof(double) * (x + 2));
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t n = 0; n < (int64_t)M->n; ++n) {
+      const double *elt = M->theta.Elogv + (size_t)n * K;
+      double *st = M->theta.snext + (size_t)n * K;
+      for (int64_t j = M->rowptr[n]; j < M->rowptr[n + 1]; ++j) {
+        uint32_t m = M->col[j];
+        uint8_t y = M->val ? M->val[j] : 1;
+        const double *elb = M->beta.Elogv + (size_t)m * K;
+        for (uint32_t k = 0; k < K; ++k) phi[k] = elt[k] + elb[k];
+        if (M->bias) { phi[K] = M->ubias.Elogv[n]; phi[K + 1] = M->ibias.Elogv[m]; }
+        orc_lognormalize(phi, x);
+        if (y > 1) for (uint32_t k = 0; k < x; ++k) phi[k] *= y;
+        double *sb = M->beta.snext + (size_t)m * K;
+        for (uint32_t k = 0; k < K; ++k) st[k] += phi[k];
+        for (uint32_t k = 0; k < K; ++k) {
+#pragma omp atomic
+          sb[k] += phi[k];
+        }
+        if (M->bias) {
+          M->ubias.snext[n] += phi[K];
+#pragma omp atomic
+          M->ibias.snext[m] += phi[K + 1];
+        }
+      }
+    }
+    free(phi);
+  }
+}
+int orc_omp_threads(void) { return omp_get_max_threads(); }
+#else
+static void sweep_nonzeros_omp(orc_model *M) { sweep_nonzeros(M); }
+int orc_omp_threads(void) { return 1; }
+#endif
+
+/* one iteration with the parallel step A (the row sweeps stay serial: they are
+   a few percent of the time) */
+void orc_model_iterate_all_cores(orc_model *M)
+{
+  void (*serial)(orc_model *) = sweep_nonzeros; (void)serial;
+  /* run step A in parallel, then the rest of the iteration as usual by
+     temporarily making the serial step A a no-op */
+  sweep_nonzeros_omp(M);
+  M->skip_step_a = 1;
+  if (M->hier) iterate_hier(M); else iterate_flat(M);
+  M->skip_step_a = 0;
 }
 
 void orc_model_iterate(orc_model *M, int n_iters)

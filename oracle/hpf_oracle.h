@@ -98,6 +98,10 @@ void orc_model_iterate(orc_model *M, int n_iters);
 /* hgaprec.cc:1439-1465 ; y is the int stored in the CountMap */
 double orc_model_heldout_sum(const orc_model *M, const uint32_t *u,
                              const uint32_t *i, const int32_t *y, uint64_t cnt);
+/* all-cores variant (OpenMP over users, atomics on item rows),
+ * for bench.py's extra cpu_baseline_all_cores figure only */
+void orc_model_iterate_all_cores(orc_model *M);
+int  orc_omp_threads(void);
 /* HGAPRec::logl hgaprec.cc:2160-2255: the variational bound written to logl.txt */
 double orc_model_elbo(orc_model *M);
 /* state access: row-major doubles; returns element count (0 if absent).

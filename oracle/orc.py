@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
     L.orc_model_iterate.argtypes = [vp, C.c_int]
     L.orc_model_heldout_sum.argtypes = [vp, u32p, u32p, i32p, C.c_uint64]
     L.orc_model_heldout_sum.restype = C.c_double
+    L.orc_model_iterate_all_cores.argtypes = [vp]
+    L.orc_omp_threads.restype = C.c_int
     L.orc_model_elbo.argtypes = [vp]
     L.orc_model_elbo.restype = C.c_double
     L.orc_model_state.argtypes = [vp, C.c_int, C.POINTER(dp)]
@@ -126,6 +128,10 @@ class Rng:
 
     def uniform_int(self, n):
         return lib().orc_rng_uniform_int(self._buf, int(n))
+
+
+def omp_threads():
+    return lib().orc_omp_threads()
 
 
 def psi(x):
@@ -237,6 +243,9 @@ class Model:
             self._m, u.ctypes.data_as(C.POINTER(C.c_uint32)),
             i.ctypes.data_as(C.POINTER(C.c_uint32)),
             y.ctypes.data_as(C.POINTER(C.c_int32)), u.size)
+
+    def iterate_all_cores(self):
+        self.L.orc_model_iterate_all_cores(self._m)
 
     def elbo(self):
         return self.L.orc_model_elbo(self._m)
