@@ -62,7 +62,7 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
                   f"({nz} nonzeros) of the same matrix, all {cfg['m']} items, K={cfg['K']}",
         "seconds": dt,
         "all_cores": {"value": nz / dt_all, "cores": orc.omp_threads(), "seconds": dt_all,
-                      "note": "same slice, step A under OpenMP (atomics on item rows), row sweeps serial"},
+                      "note": "same slice; step A under OpenMP (atomics on item rows), expectations parallel over rows"},
     }
 
 

@@ -444,9 +444,14 @@ static void gp_swap(gp *g)           /* gpbase.hh:240-246,571-577,897-903 */
   gp_set_to_prior(g);
 }
 
+static int g_parallel_sweeps = 0;   /* set only inside orc_model_iterate_all_cores */
+
 static void gp_compute_expectations(gp *g) /* gpbase.hh:248-262,579-598,912-925 */
 {
-  for (uint32_t i = 0; i < g->n; ++i)
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (g_parallel_sweeps)
+#endif
+  for (int64_t i = 0; i < (int64_t)g->n; ++i)
     for (uint32_t j = 0; j < g->k; ++j) {
       size_t e = (size_t)i * g->k + j;
       double a, b;
@@ -734,9 +739,9 @@ void orc_model_iterate_all_cores(orc_model *M)
   /* run step A in parallel, then the rest of the iteration as usual by
      temporarily making the serial step A a no-op */
   sweep_nonzeros_omp(M);
-  M->skip_step_a = 1;
+  M->skip_step_a = 1; g_parallel_sweeps = 1;
   if (M->hier) iterate_hier(M); else iterate_flat(M);
-  M->skip_step_a = 0;
+  M->skip_step_a = 0; g_parallel_sweeps = 0;
 }
 
 void orc_model_iterate(orc_model *M, int n_iters)
