@@ -239,7 +239,13 @@ def main():
         # dominant kernel of the iteration and its HBM roofline position
         kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
         kms = tm[kern + "_ms"]
-        achieved = ab[kern] / (kms * 1e-3) / 1e9
+        kname, kbytes = f"phi_pass_kernel ({kern} pass)", ab[kern]
+        if kms == 0:
+            # launch-bound workload: hpf_iterate replayed the iteration as one
+            # hipGraph, so only the whole iteration is timed
+            kms = tm["iteration_ms"]
+            kname, kbytes = "whole iteration (hipGraph replay)", ab["phi_user"] + ab["phi_item"] + ab["rows"]
+        achieved = kbytes / (kms * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists() and not custom:
@@ -265,10 +271,10 @@ def main():
                 if world > 1 else "single GPU",
             },
             "roofline": {
-                "bound": "hbm", "kernel": f"phi_pass_kernel ({kern} pass)",
+                "bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": ab[kern], "avg_launch_ms": kms,
+                "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
             "replica_check": replica_check,

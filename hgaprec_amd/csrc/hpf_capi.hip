@@ -85,6 +85,14 @@ struct hpf_handle {
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
   uint32_t ev_count = 0;                        // iterations recorded so far
   void *comm = nullptr;                 // ncclComm_t once hpf_comm_init succeeded
+  // hipGraph replay of one whole iteration for launch-bound problems (hpf_iterate,
+  // n_ranks == 1).  HPF_GRAPH=0/1 forces it off/on; default: on when the phi passes
+  // are short enough that the ~10 launches per iteration dominate (nnz <= graph_nnz_max).
+  int graph_mode = -1;                  // -1 auto, 0 off, 1 on
+  uint64_t graph_nnz_max = 4u << 20;
+  hipGraphExec_t graph_exec = nullptr;
+  bool capturing = false;               // inside stream capture: no events, no counters
+  bool ring_graphed[RING] = {};         // slot was a graph replay: only events 0 and 6 exist
   std::string err;
 };
 
@@ -511,7 +519,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
       }
     }
     // the event separates the (last) phi kernel from the combine that follows it
-    if (ph + 1 == own.phases) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
+    if (ph + 1 == own.phases && !h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
     if (own.nlong[ph]) {
       const uint32_t blocks = std::min<uint32_t>((own.nlong[ph] + 3) / 4, 16384);
       hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
@@ -548,8 +556,13 @@ int iterate_local_phi(hpf_handle *h)
 {
   int rc;
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if (h->capturing) {
+    if ((rc = run_phi(h, h->u, h->it, nullptr))) return rc;
+    return run_phi(h, h->it, h->u, nullptr);
+  }
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
+  h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
   // events: 0 start | 1 phi_user kernel done | 2 its combine done |
   //         3 phi_item kernel done | 4 its combine done | 5 user sweep | 6 item sweep
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
@@ -567,7 +580,7 @@ int iterate_local_sweep(hpf_handle *h)
 {
   int rc;
   if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
-  HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+  if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
   return HPF_OK;
 }
 
@@ -583,9 +596,61 @@ int iterate_global(hpf_handle *h)
   int rc;
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
   if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
+  if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
   h->ev_count++;
   h->iterations++;
+  return HPF_OK;
+}
+
+void drop_graph(hpf_handle *h)
+{
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+}
+
+bool want_graph(const hpf_handle *h)
+{
+  if (h->graph_mode >= 0) return h->graph_mode == 1;
+  return h->nnz <= h->graph_nnz_max;
+}
+
+// one iteration (both phi passes, both sweeps) captured once; every kernel
+// argument is a pointer or scalar that stays fixed until the CSR or the
+// exchange buffer is replaced (drop_graph there)
+int build_graph(hpf_handle *h)
+{
+  hipGraph_t g = nullptr;
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  h->capturing = true;
+  int rc = iterate_local(h);
+  if (!rc) rc = iterate_global(h);
+  h->capturing = false;
+  hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+  e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { h->graph_exec = nullptr; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+  return HPF_OK;
+}
+
+int iterate_graph(hpf_handle *h, int n_iters)
+{
+  int rc;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if ((rc = prepare_derived(h))) return rc;
+  if (!h->graph_exec && (rc = build_graph(h))) return rc;
+  for (int t = 0; t < n_iters; ++t) {
+    const uint32_t slot = h->ev_count % hpf_handle::RING;
+    h->ev = h->evr[slot];
+    h->ring_graphed[slot] = true;
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+    h->u.l_stale = h->u.es_stale = h->it.l_stale = h->it.es_stale = true;
+    h->ev_count++;
+    h->iterations++;
+  }
   return HPF_OK;
 }
 
@@ -684,6 +749,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   }
   if (const char *e = getenv("HPF_HOT_BYTES")) { long long v = atoll(e); if (v >= 0) h->hot_bytes = (uint64_t)v; }
   if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
+  if (const char *e = getenv("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
   if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
 
@@ -736,6 +802,7 @@ void hpf_destroy(hpf_handle *h)
   if (!h) return;
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  drop_graph(h);
   double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
   h->u.colsum = nullptr;
   double *icol = h->it.colsum; h->it.colsum = nullptr;
@@ -821,6 +888,7 @@ int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, co
 {
   if (!h || !rowptr) return HPF_ERR_INVALID;
   const uint32_t n = h->u.rows, m = h->it.rows;
+  drop_graph(h);
   if (rowptr[0] != 0) { h->err = "rowptr[0] must be 0"; return HPF_ERR_INVALID; }
   for (uint32_t r = 0; r < n; ++r)
     if (rowptr[r + 1] < rowptr[r]) { h->err = "rowptr not monotone"; return HPF_ERR_INVALID; }
@@ -1004,6 +1072,7 @@ int hpf_iterate(hpf_handle *h, int n_iters)
 {
   if (!h || n_iters < 0) return HPF_ERR_INVALID;
   if (h->cfg.n_ranks != 1) { h->err = "hpf_iterate needs n_ranks == 1; use iterate_local/global"; return HPF_ERR_INVALID; }
+  if (n_iters > 0 && want_graph(h)) return iterate_graph(h, n_iters);
   for (int t = 0; t < n_iters; ++t) {
     int rc;
     if ((rc = iterate_local(h))) return rc;
@@ -1260,9 +1329,12 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (uint32_t k = 0; k < n; ++k) {
-    hipEvent_t *ev = h->evr[(h->ev_count - 1 - k) % hpf_handle::RING];
-    float ms[7];
-    for (int j = 0; j < 6; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
+    const uint32_t slot = (h->ev_count - 1 - k) % hpf_handle::RING;
+    hipEvent_t *ev = h->evr[slot];
+    float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    // a graph-replayed iteration is one launch: only its total is known
+    if (!h->ring_graphed[slot])
+      for (int j = 0; j < 6; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
     HIPCHK(h, hipEventElapsedTime(&ms[6], ev[0], ev[6]));
     for (int j = 0; j < 7; ++j) acc[j] += ms[j];
   }

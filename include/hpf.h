@@ -135,7 +135,11 @@ int  hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count);
 
 /* replaces: n_iters passes of steps A-F of HGAPRec::vb_hier
  * (hgaprec.cc:1340-1414), or of vb (927-956) / vb_bias (1226-1272) without
- * -hier.  n_ranks must be 1.  Asynchronous on the handle's stream. */
+ * -hier.  n_ranks must be 1.  Asynchronous on the handle's stream.
+ * Launch-bound problems (nnz <= 4 Mi, or HPF_GRAPH=1; HPF_GRAPH=0 disables)
+ * replay one captured iteration as a hipGraph: same kernels in the same
+ * order, identical bits; such iterations report only iteration_ms in
+ * hpf_timing (the per-kernel fields read 0). */
 int  hpf_iterate(hpf_handle *h, int n_iters);
 
 /* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,

@@ -124,6 +124,33 @@ def test_run_to_run_bit_reproducible(orc):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_graph_replay_equals_eager_launches(orc, monkeypatch, bias):
+    # hpf_iterate replays one captured iteration (hipGraph) when the problem is
+    # launch-bound; same kernels, same order => identical bits, and get/set
+    # between calls still works.  Replayed iterations report only their total.
+    outs, tms = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HPF_GRAPH", mode)
+        M, D = _run_pair(orc, 400, 300, 20, 9000, True, bias, False, 5, seed=4)
+        D.iterate(2)
+        mid = D.get_state("THETA_ELOG")
+        D.set_state("THETA_ELOG", mid)             # W re-derived outside the graph
+        D.iterate(3)
+        D.iterate(1)
+        tms.append(D.mean_timing(3))
+        outs.append((D.get_state("THETA_E"), D.get_state("BETA_E"), D.get_state("XI_E"),
+                     D.get_state("BETA_ELOG"), D.get_state("THETA_RATE")))
+        if mode == "1":
+            M.iterate(6)
+            assert rel_err(outs[-1][1], M.state("BETA_E")) < RTOL
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert tms[0]["phi_user_ms"] > 0 and tms[0]["iteration_ms"] > 0
+    assert tms[1]["phi_user_ms"] == 0 and tms[1]["iteration_ms"] > 0
+    assert tms[0]["iterations"] == tms[1]["iterations"] == 6
+
+
 def test_twenty_iterations_within_contract(orc):
     # the north_star contract itself: 1e-4 relative on the factors
     M, D = _run_pair(orc, 500, 400, 20, 15000, True, False, False, 20, seed=8)
