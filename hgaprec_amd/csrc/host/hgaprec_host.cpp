@@ -71,6 +71,7 @@ int Env::parse(int argc, char **argv, bool echo, std::string *bad)
     else if (!strcmp(s, "-comm")) { comm_mode = next(); }            // extension: rccl | host
     else if (!strcmp(s, "-checkpoint")) { checkpoint_every = (uint32_t)atoi(next()); }   // extension
     else if (!strcmp(s, "-resume")) { resume = true; }                                 // extension
+    else if (!strcmp(s, "-cache")) { data_cache = true; }                              // extension
     else if (i > 0) {
       if (bad) *bad = s;
       return 1;
@@ -325,6 +326,91 @@ int Ratings::read_heldout(const std::string &path, HeldOut *out)
     out->u.push_back(raw.u[p[e]]); out->i.push_back(raw.i[p[e]]); out->y.push_back(raw.y[p[e]]);
     s = e + 1;
   }
+  return 0;
+}
+
+// ---- binary dataset image -------------------------------------------------
+namespace {
+struct CacheHeader {
+  char magic[8];                 // "HPFDATA1"
+  uint32_t cap_n, cap_m, binary, rating_threshold;
+  uint64_t src_size[3]; int64_t src_mtime_ns[3];   // train / validation / test .tsv
+  uint32_t n, m;
+  uint64_t nnz, n_validation, n_test;
+};
+const char kCacheMagic[8] = {'H', 'P', 'F', 'D', 'A', 'T', 'A', '1'};
+const uint64_t kCacheTail = 0x31444e4544465048ull;   // "HPFDEND1"
+
+bool fingerprint(const std::string &dir, CacheHeader *h)
+{
+  const char *names[3] = {"/train.tsv", "/validation.tsv", "/test.tsv"};
+  for (int j = 0; j < 3; ++j) {
+    struct stat st;
+    if (stat((dir + names[j]).c_str(), &st)) return false;
+    h->src_size[j] = (uint64_t)st.st_size;
+    h->src_mtime_ns[j] = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+  }
+  return true;
+}
+template <typename T> bool put_vec(FILE *f, const std::vector<T> &v, size_t cnt)
+{
+  return cnt == 0 || fwrite(v.data(), sizeof(T), cnt, f) == cnt;
+}
+template <typename T> bool get_vec(FILE *f, std::vector<T> *v, size_t cnt)
+{
+  v->resize(cnt);
+  return cnt == 0 || fread(v->data(), sizeof(T), cnt, f) == cnt;
+}
+}  // namespace
+
+int Ratings::save_cache(const std::string &dir) const
+{
+  CacheHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, kCacheMagic, 8);
+  h.cap_n = cap_n; h.cap_m = cap_m; h.binary = binary; h.rating_threshold = rating_threshold;
+  if (!fingerprint(dir, &h)) return -1;
+  h.n = n; h.m = m; h.nnz = col.size(); h.n_validation = validation.u.size(); h.n_test = test.u.size();
+  const std::string path = dir + "/hgaprec.cache.bin", tmp = path + ".tmp." + std::to_string((long)getpid());
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return -1;
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && put_vec(f, seq2user, n) && put_vec(f, seq2item, m) && put_vec(f, rowptr, (size_t)n + 1);
+  ok = ok && put_vec(f, col, h.nnz) && put_vec(f, val, h.nnz);
+  ok = ok && put_vec(f, validation.u, h.n_validation) && put_vec(f, validation.i, h.n_validation) && put_vec(f, validation.y, h.n_validation);
+  ok = ok && put_vec(f, test.u, h.n_test) && put_vec(f, test.i, h.n_test) && put_vec(f, test.y, h.n_test);
+  ok = ok && fwrite(&kCacheTail, 8, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); return -1; }
+  return 0;
+}
+
+int Ratings::load_cache(const std::string &dir)
+{
+  FILE *f = fopen((dir + "/hgaprec.cache.bin").c_str(), "rb");
+  if (!f) return 1;
+  CacheHeader h, want;
+  memset(&want, 0, sizeof want);
+  bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, kCacheMagic, 8) && fingerprint(dir, &want);
+  ok = ok && h.cap_n == cap_n && h.cap_m == cap_m && h.binary == (uint32_t)binary && h.rating_threshold == rating_threshold;
+  for (int j = 0; ok && j < 3; ++j) ok = h.src_size[j] == want.src_size[j] && h.src_mtime_ns[j] == want.src_mtime_ns[j];
+  Ratings t;                                    // only committed when the whole image checks out
+  ok = ok && get_vec(f, &t.seq2user, h.n) && get_vec(f, &t.seq2item, h.m) && get_vec(f, &t.rowptr, (size_t)h.n + 1);
+  ok = ok && get_vec(f, &t.col, h.nnz) && get_vec(f, &t.val, h.nnz);
+  ok = ok && get_vec(f, &t.validation.u, h.n_validation) && get_vec(f, &t.validation.i, h.n_validation) && get_vec(f, &t.validation.y, h.n_validation);
+  ok = ok && get_vec(f, &t.test.u, h.n_test) && get_vec(f, &t.test.i, h.n_test) && get_vec(f, &t.test.y, h.n_test);
+  uint64_t tail = 0;
+  ok = ok && fread(&tail, 8, 1, f) == 1 && tail == kCacheTail;
+  fclose(f);
+  ok = ok && t.rowptr.front() == 0 && (uint64_t)t.rowptr.back() == h.nnz;
+  if (!ok) return 1;
+  n = h.n; m = h.m; nratings = h.nnz;
+  seq2user.swap(t.seq2user); seq2item.swap(t.seq2item); rowptr.swap(t.rowptr); col.swap(t.col); val.swap(t.val);
+  validation = std::move(t.validation); test = std::move(t.test);
+  user2seq = IdMap(); item2seq = IdMap();
+  for (uint32_t s = 0; s < n; ++s) user2seq.put(seq2user[s], s);
+  for (uint32_t s = 0; s < m; ++s) item2seq.put(seq2item[s], s);
+  heldout_loaded = true;
   return 0;
 }
 

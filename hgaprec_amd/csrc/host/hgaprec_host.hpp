@@ -35,6 +35,11 @@ struct Env {
   // main.cc:137-140): -checkpoint N writes <outdir>/checkpoint.r<rank>of<world>.bin
   // every N iterations, -resume continues from it
   uint32_t checkpoint_every = 0; bool resume = false;
+  // extension (the reference reads TSV only): -cache keeps a
+  // binary image of the parsed dataset (CSR + id maps + held-out sets) in
+  // <dir>/hgaprec.cache.bin and loads it instead of the three TSVs while their
+  // sizes / mtimes and -n -m -binary-data -rating-threshold are unchanged
+  bool data_cache = false;
 
   std::string prefix;          // output directory (Env::prefix)
   FILE *plogf = nullptr;       // param.txt
@@ -87,6 +92,14 @@ struct Ratings {
   // ratings.cc:217-271
   int write_marginals(const std::string &byusers, const std::string &byitems,
                       uint32_t *longest_users, uint32_t *longest_items) const;
+
+  // binary dataset image (extension): everything read_train + both
+  // read_heldout calls produce.  dir = the -dir argument (source TSVs are
+  // fingerprinted by size and mtime).  load: 0 = loaded, 1 = absent / stale /
+  // other parameters / truncated (parse the TSVs instead).  save: 0 or -1.
+  bool heldout_loaded = false;
+  int save_cache(const std::string &dir) const;
+  int load_cache(const std::string &dir);
 
  // open-addressing id -> seq maps (std::map in the reference; only lookups
   // and insertion order matter)

@@ -86,12 +86,18 @@ struct Driver {
       }
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
-    int rc = rt.read_heldout(env.datfname + "/validation.tsv", &rt.validation);
-    assert(rc != -1);
-    if (rc) exit(-1);
-    rc = rt.read_heldout(env.datfname + "/test.tsv", &rt.test);
-    assert(rc != -1);
-    if (rc) exit(-1);
+    if (!rt.heldout_loaded) {                     // else: came with the -cache image
+      int rc = rt.read_heldout(env.datfname + "/validation.tsv", &rt.validation);
+      assert(rc != -1);
+      if (rc) exit(-1);
+      rc = rt.read_heldout(env.datfname + "/test.tsv", &rt.test);
+      assert(rc != -1);
+      if (rc) exit(-1);
+      if (env.data_cache && root()) {
+        if (rt.save_cache(env.datfname)) env.lerr("-cache: cannot write %s/hgaprec.cache.bin", env.datfname.c_str());
+        else env.lerr("-cache: wrote %s/hgaprec.cache.bin", env.datfname.c_str());
+      }
+    }
     if (root()) {
       printf("+ loaded validation and test sets from %s\n", env.datfname.c_str());
       fflush(stdout);
@@ -120,7 +126,7 @@ struct Driver {
     cfg.hier = env.hier; cfg.bias = env.bias; cfg.binary = env.binary_data;
     cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = (uint32_t)comm.world; cfg.rank = (uint32_t)comm.rank;
     cfg.s_prior = 0.3; cfg.r_prior = 0.3;
-    rc = hpf_create(&cfg, &h);
+    int rc = hpf_create(&cfg, &h);
     if (rc) die("hpf_create (is an MI355X visible? there is no CPU fallback)", rc);
     std::vector<int64_t> rp(rt.rowptr.begin() + lo, rt.rowptr.begin() + hi + 1);
     const int64_t base = rp[0];
@@ -632,7 +638,10 @@ int main(int argc, char **argv)
   ratings.cap_n = env.n; ratings.cap_m = env.m;
   ratings.binary = env.binary_data; ratings.rating_threshold = env.rating_threshold;
   if (rank == 0) { fprintf(stdout, "+ reading ratings dataset from %s\n", env.datfname.c_str()); fflush(stdout); }
-  int rc = ratings.read_train(env.datfname + "/train.tsv");
+  int rc = 0;
+  if (env.data_cache && ratings.load_cache(env.datfname) == 0) {
+    if (rank == 0) env.lerr("-cache: loaded %s/hgaprec.cache.bin", env.datfname.c_str());
+  } else rc = ratings.read_train(env.datfname + "/train.tsv");
   if (rc) exit(-1);
   if (rank == 0) {
     env.plog("training ratings", (uint32_t)ratings.nratings);

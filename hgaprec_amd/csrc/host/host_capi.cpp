@@ -58,6 +58,15 @@ const uint32_t *hg_ratings_heldout_i(const Ratings *r, int w) { return (w ? r->t
 const int32_t *hg_ratings_heldout_y(const Ratings *r, int w) { return (w ? r->test : r->validation).y.data(); }
 int hg_ratings_write_marginals(const Ratings *r, const char *bu, const char *bi)
 { return r->write_marginals(bu, bi, nullptr, nullptr); }
+int hg_ratings_save_cache(const Ratings *r, const char *dir) { return r->save_cache(dir); }
+int hg_ratings_load_cache(Ratings *r, const char *dir) { return r->load_cache(dir); }
+int hg_ratings_test_users(const Ratings *r, const char *path, uint32_t *out, uint32_t cap)
+{
+  std::vector<uint32_t> ids;
+  if (r->read_test_users(path, &ids)) return -1;
+  for (uint32_t j = 0; j < ids.size() && j < cap; ++j) out[j] = ids[j];
+  return (int)ids.size();
+}
 
 void hg_mt_u32(double seed, uint32_t count, uint32_t *out)
 {

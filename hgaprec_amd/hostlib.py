@@ -42,6 +42,9 @@ def lib():
     L.hg_ratings_heldout_i.argtypes = [vp, C.c_int]; L.hg_ratings_heldout_i.restype = u32p
     L.hg_ratings_heldout_y.argtypes = [vp, C.c_int]; L.hg_ratings_heldout_y.restype = C.POINTER(C.c_int32)
     L.hg_ratings_write_marginals.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.hg_ratings_save_cache.argtypes = [vp, C.c_char_p]
+    L.hg_ratings_load_cache.argtypes = [vp, C.c_char_p]
+    L.hg_ratings_test_users.argtypes = [vp, C.c_char_p, u32p, C.c_uint32]
     L.hg_mt_u32.argtypes = [C.c_double, C.c_uint32, u32p]
     L.hg_digamma.argtypes = [C.c_double]; L.hg_digamma.restype = C.c_double
     L.hg_state_new.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
@@ -123,6 +126,19 @@ class Ratings:
 
     def write_marginals(self, byusers, byitems):
         return self.L.hg_ratings_write_marginals(self._r, str(byusers).encode(), str(byitems).encode())
+
+    def save_cache(self, data_dir):
+        """-cache: binary image of the parsed dataset in <data_dir>/hgaprec.cache.bin"""
+        return self.L.hg_ratings_save_cache(self._r, str(data_dir).encode())
+
+    def load_cache(self, data_dir):
+        """0 = loaded; 1 = absent, stale (TSV size/mtime), other parameters or damaged"""
+        return self.L.hg_ratings_load_cache(self._r, str(data_dir).encode())
+
+    def test_users(self, path):
+        out = np.empty(max(self.n, 1), np.uint32)
+        c = self.L.hg_ratings_test_users(self._r, str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size)
+        return None if c < 0 else out[:c].copy()
 
     def __del__(self):
         try:

@@ -228,6 +228,49 @@ def test_checkpoint_and_resume(tmp_path):
     assert r.returncode != 0
 
 
+def test_dataset_cache_runs_are_identical(tmp_path):
+    """-cache (extension): first run parses the TSVs and writes the binary image,
+    the second loads it; every output file must be byte-identical (same CSR,
+    same id maps, same held-out sets => same everything), also with 2 ranks."""
+    n, m, K = 300, 200, 6
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=23)
+    ids = sorted({int(l.split("\t")[0]) for l in (data / "test.tsv").read_text().splitlines()})
+    (data / "test_users.tsv").write_text("".join(f"{u}\n" for u in ids[:40]))
+    base = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "5", "-rfreq", "5", "-hier",
+            "-max-iterations", "10"]
+    outs = []
+    for tag, extra in (("plain", []), ("write", ["-cache"]), ("load", ["-cache"]),
+                       ("load2", ["-cache", "-ngpus", "2", "-device", "0", "-comm", "host"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([str(EXE)] + base + extra, cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out = [p for p in d.iterdir() if p.is_dir()][0]
+        log = (out / "infer.log").read_text()
+        if tag == "write":
+            assert "-cache: wrote" in log and (data / "hgaprec.cache.bin").exists()
+        if tag.startswith("load"):
+            assert "-cache: loaded" in log and "-cache: wrote" not in log
+        outs.append(out)
+    names = ["validation.txt", "test.txt", "byusers.tsv", "byitems.tsv", "precision.txt", "htheta.tsv", "hbeta.tsv",
+             "htheta_shape.tsv", "hbeta_rate.tsv", "thetarate.tsv", "betarate_rate.tsv"]
+    for nm in names:
+        ref = (outs[0] / nm).read_text().splitlines()
+        for o in outs[1:3]:
+            got = (o / nm).read_text().splitlines()
+            if nm in ("validation.txt", "test.txt"):          # column 2 is wall-clock seconds
+                strip = lambda ls: [l.split("\t")[:1] + l.split("\t")[2:] for l in ls]
+                assert strip(got) == strip(ref), nm
+            else:
+                assert got == ref, nm
+    # two ranks on the cached dataset: same integers, values within the sharded-sum tolerance
+    for nm in ("htheta.tsv", "hbeta.tsv"):
+        ia, va = read_tsv(outs[0] / nm)
+        ib, vb = read_tsv(outs[3] / nm)
+        assert np.array_equal(ia, ib) and np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(va))
+
+
 def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
     """BASELINE config C1: the MovieLens-1M stand-in (the real example/ tarball is
     not in the reference mount): 6040 x 3681, ~1.0M ratings split 80/1/19,

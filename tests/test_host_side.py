@@ -150,6 +150,45 @@ def test_reader_edge_cases(orc, tmp_path):
     assert list(zip(tu, ti, ty)) == [(2, 0, 260), (4, 1, 4)]  # map order; int kept, wrapped at use
 
 
+def test_dataset_cache_round_trip_and_staleness(orc, tmp_path):
+    # -cache (extension): the binary image must give back exactly
+    # what the three TSV parses gave, and must be refused when anything it was
+    # built from changed
+    rng = np.random.default_rng(3)
+    train = [(int(u), int(i), int(r)) for u, i, r in
+             zip(rng.integers(1000, 1400, 6000), rng.integers(1, 300, 6000), rng.integers(0, 7, 6000))]
+    valid = [(int(u), int(i), int(r)) for u, i, r in
+             zip(rng.integers(1000, 1420, 400), rng.integers(1, 320, 400), rng.integers(0, 6, 400))]
+    test = valid[::-1][:150] + [(1001, 5, 2)]
+    H, O = _both_readers(orc, tmp_path, train, valid, test, 1000, 1000)
+    assert H.save_cache(tmp_path) == 0
+    C = hostlib.Ratings(1000, 1000, False, 1)
+    assert C.load_cache(tmp_path) == 0
+    _assert_same(C, O)
+    # the id -> seq maps are rebuilt: test_users.tsv lookups work on a cached dataset
+    (tmp_path / "test_users.tsv").write_text("1001\n999999\n%d\n1001\n" % int(H.seq2user()[7]))
+    assert np.array_equal(C.test_users(tmp_path / "test_users.tsv"), H.test_users(tmp_path / "test_users.tsv"))
+    assert len(C.test_users(tmp_path / "test_users.tsv")) == 2
+    # other parameters: refused
+    assert hostlib.Ratings(999, 1000, False, 1).load_cache(tmp_path) == 1
+    assert hostlib.Ratings(1000, 1000, True, 1).load_cache(tmp_path) == 1
+    assert hostlib.Ratings(1000, 1000, False, 2).load_cache(tmp_path) == 1
+    # damaged image: refused (and nothing half-loaded)
+    img = (tmp_path / "hgaprec.cache.bin").read_bytes()
+    (tmp_path / "hgaprec.cache.bin").write_bytes(img[:-9])
+    D = hostlib.Ratings(1000, 1000, False, 1)
+    assert D.load_cache(tmp_path) == 1 and D.n == 0 and D.nnz == 0
+    (tmp_path / "hgaprec.cache.bin").write_bytes(img)
+    assert hostlib.Ratings(1000, 1000, False, 1).load_cache(tmp_path) == 0
+    # a source file changed after the image was written: refused
+    with open(tmp_path / "validation.tsv", "a") as f:
+        f.write("1001\t7\t3\n")
+    assert hostlib.Ratings(1000, 1000, False, 1).load_cache(tmp_path) == 1
+    # no image at all
+    (tmp_path / "hgaprec.cache.bin").unlink()
+    assert hostlib.Ratings(1000, 1000, False, 1).load_cache(tmp_path) == 1
+
+
 def test_reader_capacity_limits(orc, tmp_path):
     rng = np.random.default_rng(5)
     train = [(int(u), int(i), int(y)) for u, i, y in
