@@ -196,12 +196,13 @@ def main():
         if not use_dist:
             D.iterate(1)
         else:
-            # the item shape sums (m*ld doubles) are final after the phi passes:
-            # their all-reduce runs on RCCL's stream while the user sweep runs
-            # on ours; sum_u E[theta] (ld doubles) follows in a second, tiny one
-            D.iterate_local_phi()
+            # the item shape sums (m*ld doubles) are final after the item-major phi
+            # pass, which runs first: their all-reduce runs on RCCL's stream while
+            # the user-major pass and the user sweep run on ours; sum_u E[theta]
+            # (ld doubles) follows in a second, tiny one
+            D.iterate_local_items()
             w = dist.all_reduce(x_items, async_op=True)
-            D.iterate_local_sweep()
+            D.iterate_local_users()
             dist.all_reduce(x_tail)
             w.wait()
             D.iterate_global()

@@ -31,10 +31,11 @@ STATE = {n: i for i, n in enumerate(STATE_NAMES)}
 EXPORTS = [
     "hpf_abi_version", "hpf_strerror", "hpf_last_error", "hpf_create", "hpf_destroy",
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
-    "hpf_iterate_local", "hpf_iterate_local_phi", "hpf_iterate_local_sweep", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
+    "hpf_iterate_local", "hpf_iterate_local_items", "hpf_iterate_local_users",
+    "hpf_iterate_local_phi", "hpf_iterate_local_sweep", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
     "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
-    "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
+    "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_items_begin", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
     "hpf_algorithmic_bytes",
 ]
 
@@ -92,6 +93,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_iterate_local.argtypes = [vp]
     lib.hpf_iterate_global.argtypes = [vp]
     lib.hpf_iterate_local_phi.argtypes = [vp]
+    lib.hpf_iterate_local_items.argtypes = [vp]
+    lib.hpf_iterate_local_users.argtypes = [vp]
     lib.hpf_iterate_local_sweep.argtypes = [vp]
     lib.hpf_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.hpf_bind_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
@@ -105,6 +108,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_comm_unique_id.argtypes = [vp]
     lib.hpf_comm_init.argtypes = [vp, vp]
     lib.hpf_allreduce_exchange.argtypes = [vp]
+    lib.hpf_allreduce_items_begin.argtypes = [vp]
     lib.hpf_exchange_read.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_exchange_write.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_synchronize.argtypes = [vp]
@@ -214,6 +218,12 @@ class Hpf:
     def iterate_local(self):
         self._check(self.lib.hpf_iterate_local(self._h))
 
+    def iterate_local_items(self):
+        self._check(self.lib.hpf_iterate_local_items(self._h))
+
+    def iterate_local_users(self):
+        self._check(self.lib.hpf_iterate_local_users(self._h))
+
     def iterate_local_phi(self):
         self._check(self.lib.hpf_iterate_local_phi(self._h))
 
@@ -251,6 +261,9 @@ class Hpf:
     def comm_init(self, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.lib.hpf_comm_init(self._h, buf))
+
+    def allreduce_items_begin(self):
+        self._check(self.lib.hpf_allreduce_items_begin(self._h))
 
     def allreduce_exchange(self):
         self._check(self.lib.hpf_allreduce_exchange(self._h))

@@ -171,9 +171,15 @@ struct Driver {
   void iterate() {
     int rc;
     if (comm.world == 1) { if ((rc = hpf_iterate(h, 1))) die("hpf_iterate", rc); return; }
-    if ((rc = hpf_iterate_local(h))) die("hpf_iterate_local", rc);
-    if (use_rccl) { if ((rc = hpf_allreduce_exchange(h))) die("hpf_allreduce_exchange", rc); }
-    else {
+    if (use_rccl) {
+      // the all-reduce of the item sums (m*ld doubles) overlaps the user-major
+      // pass and the user sweep; the [ld] tail follows
+      if ((rc = hpf_iterate_local_items(h))) die("hpf_iterate_local_items", rc);
+      if ((rc = hpf_allreduce_items_begin(h))) die("hpf_allreduce_items_begin", rc);
+      if ((rc = hpf_iterate_local_users(h))) die("hpf_iterate_local_users", rc);
+      if ((rc = hpf_allreduce_exchange(h))) die("hpf_allreduce_exchange", rc);
+    } else {
+      if ((rc = hpf_iterate_local(h))) die("hpf_iterate_local", rc);
       void *p; size_t cnt;
       hpf_exchange_buffer(h, &p, &cnt);
       xbuf.resize(cnt);

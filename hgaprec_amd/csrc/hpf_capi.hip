@@ -85,6 +85,11 @@ struct hpf_handle {
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
   uint32_t ev_count = 0;                        // iterations recorded so far
   void *comm = nullptr;                 // ncclComm_t once hpf_comm_init succeeded
+  // the item part of the exchange buffer is reduced on its own stream so that
+  // the user-side half of the iteration overlaps it (hpf_allreduce_items_begin)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_reduced = nullptr;
+  bool items_reduce_pending = false;
   // hipGraph replay of one whole iteration for launch-bound problems (hpf_iterate,
   // n_ranks == 1).  HPF_GRAPH=0/1 forces it off/on; default: on when the phi passes
   // are short enough that the ~10 launches per iteration dominate (nnz <= graph_nnz_max).
@@ -92,6 +97,7 @@ struct hpf_handle {
   uint64_t graph_nnz_max = 4u << 20;
   hipGraphExec_t graph_exec = nullptr;
   bool capturing = false;               // inside stream capture: no events, no counters
+  int phase = 0;                        // 0 idle | 1 items pass done | 2 users pass done | 3 user sweep done
   bool ring_graphed[RING] = {};         // slot was a graph replay: only events 0 and 6 exist
   std::string err;
 };
@@ -551,53 +557,82 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   return check_launch(h, "row sweep");
 }
 
-// first half of the rank-local work: both phi passes (step A)
-int iterate_local_phi(hpf_handle *h)
+// Step A is two independent gather passes over the same W_theta / W_beta: the
+// item-major one (beta shape sums, straight into the exchange buffer) runs
+// first so that, with several ranks, its all-reduce can overlap the whole
+// user-side half of the iteration.
+// events: 0 start | 1 phi_item kernel done | 2 its combine done |
+//         3 phi_user kernel done | 4 its combine done | 5 user sweep | 6 item sweep
+int phi_items(hpf_handle *h)
 {
   int rc;
+  if (h->capturing) return run_phi(h, h->it, h->u, nullptr);
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
-  if (h->capturing) {
-    if ((rc = run_phi(h, h->u, h->it, nullptr))) return rc;
-    return run_phi(h, h->it, h->u, nullptr);
-  }
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
   h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
-  // events: 0 start | 1 phi_user kernel done | 2 its combine done |
-  //         3 phi_item kernel done | 4 its combine done | 5 user sweep | 6 item sweep
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  if ((rc = run_phi(h, h->u, h->it, h->ev[1]))) return rc;   // step A, theta shape sums
+  if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;   // step A, beta shape sums
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-  if ((rc = run_phi(h, h->it, h->u, h->ev[3]))) return rc;   // step A, beta shape sums
-  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+  h->phase = 1;
   return HPF_OK;
 }
 
-// second half: steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits
-// d = sum_u E[theta] into the tail of the exchange buffer.  Does not touch the
-// item part of the exchange buffer, so its all-reduce may already be running.
-int iterate_local_sweep(hpf_handle *h)
+int phi_users(hpf_handle *h)
 {
   int rc;
-  if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
-  if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+  if (h->capturing) return run_phi(h, h->u, h->it, nullptr);
+  if (h->phase != 1) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
+  if ((rc = run_phi(h, h->u, h->it, h->ev[3]))) return rc;   // step A, theta shape sums
+  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+  h->phase = 2;
   return HPF_OK;
+}
+
+// steps B (+D user, E): theta rate uses c = sum_i E[beta]; emits
+// d = sum_u E[theta] into the tail of the exchange buffer.  Does not touch the
+// item part of the exchange buffer, so its all-reduce may already be running.
+int sweep_users(hpf_handle *h)
+{
+  int rc;
+  if (!h->capturing && h->phase != 2) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
+  if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
+  if (h->capturing) return HPF_OK;
+  HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
+  h->phase = 3;
+  return HPF_OK;
+}
+
+int iterate_local_phi(hpf_handle *h)
+{
+  int rc;
+  if ((rc = phi_items(h))) return rc;
+  return phi_users(h);
+}
+
+int iterate_local_users(hpf_handle *h)
+{
+  int rc;
+  if ((rc = phi_users(h))) return rc;
+  return sweep_users(h);
 }
 
 int iterate_local(hpf_handle *h)
 {
   int rc;
   if ((rc = iterate_local_phi(h))) return rc;
-  return iterate_local_sweep(h);
+  return sweep_users(h);
 }
 
 int iterate_global(hpf_handle *h)
 {
   int rc;
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
+  if (!h->capturing && h->phase != 3) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
   if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
   if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+  h->phase = 0;
   h->ev_count++;
   h->iterations++;
   return HPF_OK;
@@ -803,6 +838,11 @@ void hpf_destroy(hpf_handle *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   drop_graph(h);
+  if (h->comm_stream) {
+    (void)hipStreamSynchronize(h->comm_stream);
+    (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_reduced);
+    (void)hipStreamDestroy(h->comm_stream);
+  }
   double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
   h->u.colsum = nullptr;
   double *icol = h->it.colsum; h->it.colsum = nullptr;
@@ -851,13 +891,46 @@ int hpf_comm_init(hpf_handle *h, const void *id)
   return HPF_OK;
 }
 
+int hpf_allreduce_items_begin(hpf_handle *h)
+{
+  if (!h) return HPF_ERR_INVALID;
+  if (!h->comm) { h->err = "hpf_comm_init has not been called"; return HPF_ERR_STATE; }
+  if (h->phase != 1) { h->err = "hpf_allreduce_items_begin follows hpf_iterate_local_items"; return HPF_ERR_STATE; }
+  if (!h->comm_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_reduced, hipEventDisableTiming));
+  }
+  HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));                 // item sums are final here
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+  const size_t items = (size_t)h->it.rows * h->ld;
+  const int rc = g_rccl.AllReduce(h->exch, h->exch, items, 8, 0, h->comm, (void *)h->comm_stream);
+  if (rc != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
+  h->items_reduce_pending = true;
+  return HPF_OK;
+}
+
 int hpf_allreduce_exchange(hpf_handle *h)
 {
   if (!h) return HPF_ERR_INVALID;
   if (!h->comm) { h->err = "hpf_comm_init has not been called"; return HPF_ERR_STATE; }
-  // ncclDouble = 8, ncclSum = 0 (rccl.h:448,467); in place, on the stream the kernels use
-  const int rc = g_rccl.AllReduce(h->exch, h->exch, h->exch_count, 8, 0, h->comm, (void *)h->stream);
+  // ncclDouble = 8, ncclSum = 0 (rccl.h:448,467); in place
+  if (!h->items_reduce_pending) {               // everything at once, on the stream the kernels use
+    const int rc = g_rccl.AllReduce(h->exch, h->exch, h->exch_count, 8, 0, h->comm, (void *)h->stream);
+    if (rc != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
+    return HPF_OK;
+  }
+  // the item part is already on its way: add the [ld] tail (sum_u E[theta]), then
+  // let the kernels' stream wait for both
+  const size_t items = (size_t)h->it.rows * h->ld;
+  HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+  const int rc = g_rccl.AllReduce(h->exch + items, h->exch + items, h->exch_count - items, 8, 0, h->comm,
+                                  (void *)h->comm_stream);
   if (rc != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
+  HIPCHK(h, hipEventRecord(h->ev_reduced, h->comm_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_reduced, 0));
+  h->items_reduce_pending = false;
   return HPF_OK;
 }
 
@@ -1083,7 +1156,9 @@ int hpf_iterate(hpf_handle *h, int n_iters)
 
 int hpf_iterate_local(hpf_handle *h) { return h ? iterate_local(h) : HPF_ERR_INVALID; }
 int hpf_iterate_local_phi(hpf_handle *h) { return h ? iterate_local_phi(h) : HPF_ERR_INVALID; }
-int hpf_iterate_local_sweep(hpf_handle *h) { return h ? iterate_local_sweep(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_sweep(hpf_handle *h) { return h ? sweep_users(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_items(hpf_handle *h) { return h ? phi_items(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_users(hpf_handle *h) { return h ? iterate_local_users(h) : HPF_ERR_INVALID; }
 int hpf_iterate_global(hpf_handle *h) { return h ? iterate_global(h) : HPF_ERR_INVALID; }
 
 int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const int32_t *y,
@@ -1338,10 +1413,10 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
     HIPCHK(h, hipEventElapsedTime(&ms[6], ev[0], ev[6]));
     for (int j = 0; j < 7; ++j) acc[j] += ms[j];
   }
-  out->phi_user_ms = (float)(acc[0] / n);
-  out->combine_user_ms = (float)(acc[1] / n);
-  out->phi_item_ms = (float)(acc[2] / n);
-  out->combine_item_ms = (float)(acc[3] / n);
+  out->phi_item_ms = (float)(acc[0] / n);
+  out->combine_item_ms = (float)(acc[1] / n);
+  out->phi_user_ms = (float)(acc[2] / n);
+  out->combine_user_ms = (float)(acc[3] / n);
   out->sweep_user_ms = (float)(acc[4] / n);
   out->sweep_item_ms = (float)(acc[5] / n);
   out->iteration_ms = (float)(acc[6] / n);

@@ -86,7 +86,8 @@ class Exchange:
 
 def iterate(engine, exchange: Exchange | None, n_iters: int = 1):
     """n_iters CAVI iterations of one rank of a sharded run (bench.py overlaps the
-    big all-reduce with the user sweep through iterate_local_phi / _sweep)"""
+    big all-reduce with the user-major pass and the user sweep through
+    iterate_local_items / iterate_local_users)"""
     for _ in range(n_iters):
         engine.iterate_local()
         if exchange is not None:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 1
+#define HPF_ABI_VERSION 2
 
 typedef struct hpf_handle hpf_handle;
 
@@ -145,11 +145,19 @@ int  hpf_iterate(hpf_handle *h, int n_iters);
 /* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,
  * E) and the local partial sums ... */
 int  hpf_iterate_local(hpf_handle *h);
-/* hpf_iterate_local in two halves, for callers that overlap communication:
- * _phi runs the two phi passes -- after it the first n_items*ld doubles of the
- * exchange buffer (the item shape sums) are final and their all-reduce may
- * start; _sweep runs the user sweep, which only writes the last ld doubles
- * (sum_u E[theta_u,:]), reduced in a second, tiny all-reduce. */
+/* hpf_iterate_local in pieces, for callers that overlap communication.  Step A
+ * is two independent passes over the same W: the item-major one runs first.
+ *   _items : item phi pass -- after it the first n_items*ld doubles of the
+ *            exchange buffer (the item shape sums) are final and their
+ *            all-reduce may start;
+ *   _users : user phi pass + user sweep (B, D-user, E); only writes the last
+ *            ld doubles (sum_u E[theta_u,:]), reduced in a second, tiny
+ *            all-reduce.  (_phi = _items + the user phi pass, _sweep = the
+ *            user sweep alone: the same work cut after step A instead.)
+ * Order per iteration: _items, _users (or _phi, _sweep), hpf_iterate_global;
+ * anything else returns HPF_ERR_STATE. */
+int  hpf_iterate_local_items(hpf_handle *h);
+int  hpf_iterate_local_users(hpf_handle *h);
 int  hpf_iterate_local_phi(hpf_handle *h);
 int  hpf_iterate_local_sweep(hpf_handle *h);
 /* ... the caller sum-all-reduces this device buffer of `count` doubles in
@@ -167,10 +175,15 @@ int  hpf_iterate_global(hpf_handle *h);
  * HPF_COMM_ID_BYTES bytes to the others by any means; every rank then calls
  * hpf_comm_init (collective) once, and hpf_allreduce_exchange between
  * iterate_local and iterate_global.  = ncclGetUniqueId / ncclCommInitRank /
- * ncclAllReduce(ncclDouble, ncclSum) in place on the handle's stream. */
+ * ncclAllReduce(ncclDouble, ncclSum) in place on the handle's stream.
+ * Overlapped form: hpf_iterate_local_items, hpf_allreduce_items_begin (the
+ * item part goes out on a second, library-owned stream), hpf_iterate_local_users
+ * (runs meanwhile), hpf_allreduce_exchange (adds the tail and makes the
+ * handle's stream wait for both), hpf_iterate_global. */
 #define HPF_COMM_ID_BYTES 128
 int  hpf_comm_unique_id(void *id_out);
 int  hpf_comm_init(hpf_handle *h, const void *id);
+int  hpf_allreduce_items_begin(hpf_handle *h);
 int  hpf_allreduce_exchange(hpf_handle *h);
 /* host copies of the exchange buffer (host-staged reduction, tests) */
 int  hpf_exchange_read(hpf_handle *h, double *host, size_t count);

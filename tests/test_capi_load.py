@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()
     for name in header_functions():
         assert getattr(lib, name) is not None
-    assert lib.hpf_abi_version() == 1
+    hdr = (Path(capi.__file__).resolve().parent.parent / "include" / "hpf.h").read_text()
+    assert lib.hpf_abi_version() == int(re.search(r"#define HPF_ABI_VERSION (\d+)", hdr).group(1)) == 2
     assert lib.hpf_strerror(0) == b"ok"
     assert b"device" in lib.hpf_strerror(-2)
 

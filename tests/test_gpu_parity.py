@@ -279,6 +279,51 @@ def test_library_rccl_allreduce_world1(orc):
     assert np.array_equal(D.exchange_read(), before * 2.0)
 
 
+def test_overlapped_exchange_sequence_world1(orc):
+    # the order `hgaprec -ngpus N` uses, on a 1-rank communicator: item pass,
+    # all-reduce of the item sums started on the library's second stream, user
+    # pass + user sweep meanwhile, tail all-reduce, replicated item sweep.
+    # Must equal plain hpf_iterate bit for bit (same kernels, same order).
+    from hgaprec_amd.capi import Hpf
+    M, D = _run_pair(orc, 300, 200, 20, 7000, True, True, False, 4, seed=6)
+    _, D2 = _run_pair(orc, 300, 200, 20, 7000, True, True, False, 4, seed=6)
+    D.comm_init(Hpf.comm_unique_id())
+    for _ in range(4):
+        D.iterate_local_items()
+        D.allreduce_items_begin()
+        D.iterate_local_users()
+        D.allreduce_exchange()
+        D.iterate_global()
+    D2.iterate(4)
+    M.iterate(4)
+    for w in compare_states(True, True):
+        assert np.array_equal(D.get_state(w), D2.get_state(w)), w
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+    t = D.last_timing()
+    assert t["phi_item_ms"] > 0 and t["phi_user_ms"] > 0 and t["sweep_item_ms"] > 0
+
+
+def test_iteration_pieces_and_their_call_order(orc):
+    from hgaprec_amd.capi import HpfError
+    M, D = _run_pair(orc, 200, 150, 8, 4000, True, False, False, 3, seed=9)
+    _, D2 = _run_pair(orc, 200, 150, 8, 4000, True, False, False, 3, seed=9)
+    for bad in (D.iterate_global, D.iterate_local_users, D.iterate_local_sweep):
+        with pytest.raises(HpfError, match="call order"):
+            bad()
+    D.iterate_local_items()
+    with pytest.raises(HpfError, match="call order"):
+        D.iterate_local_sweep()                        # the user pass has not run yet
+    D.iterate_local_users()
+    with pytest.raises(HpfError, match="call order"):
+        D.iterate_local_users()
+    D.iterate_global()
+    D.iterate_local_phi(); D.iterate_local_sweep(); D.iterate_global()      # the other cut
+    D.iterate_local(); D.iterate_global()
+    D2.iterate(3)
+    for w in compare_states(True, False):
+        assert np.array_equal(D.get_state(w), D2.get_state(w)), w
+
+
 @pytest.mark.parametrize("K,bias", [(1, False), (1, True), (2, False), (333, False), (512, False), (510, True),
                                     (700, False), (1024, False), (1022, True)])
 def test_extreme_factor_counts(orc, K, bias):
