@@ -8,7 +8,7 @@ stored as hex strings (float.hex) so the fixtures are bit-exact.  The rest of
 the reference needs GSL (absent here), so there are no end-to-end fixtures:
 see DESIGN.md "Oracle".
 
-    python tools/make_golden.py        # rewrites tests/golden/
+    python tests/golden/make_golden.py        # rewrites tests/golden/
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 REFPART = ROOT / "oracle" / "_ref" / "refpart"
 GOLD = ROOT / "tests" / "golden"
 

@@ -378,7 +378,7 @@ def test_f32_stored_w_experimental_mode(orc, K, hier, bias):
     """EXPERIMENTAL storage mode (hpf_config.w_storage = 1; never the default):
     W = exp(Elog - rowmax) kept in fp32, arithmetic and accumulators fp64.  Each
     W carries a 2^-24 relative rounding which the CAVI map amplifies: measured
-    (tools/w32_error_growth.py) 3e-7 after 5 sweeps, 2e-5 after 20, 1e-3 after
+    (tests/w32_error_growth.py) 3e-7 after 5 sweeps, 2e-5 after 20, 1e-3 after
     60, up to 1e-1 after 300 -- it leaves the 1e-4 contract after ~30 sweeps,
     which is why the product stores W in fp64 (drift 1e-9 at 300 sweeps).
     The mode itself must work, be deterministic and be accurate for short runs."""

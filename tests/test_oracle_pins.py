@@ -1,7 +1,7 @@
 """CPU: pin the oracle (oracle/liborc.so) to everything pinnable here.
 
  * golden vectors produced by the reference's own GSL-free code (matrix.hh,
-   env.hh, log.cc compiled in place -> tools/make_golden.py): bit-exact;
+   env.hh, log.cc compiled in place -> tests/golden/make_golden.py): bit-exact;
  * published known answers for MT19937 (GSL manual: first default-seed output
    4293858116; C++ standard: 10000th output of seed 5489 is 4123659995) and
    numpy's RandomState (same generator + init_genrand seeding);
