@@ -236,7 +236,7 @@ int Ratings::read_generic(FILE *f, HeldOut *out)
     if (!first && tk.at_eof()) break;           // the trailing "\n" directive ate the whitespace
     first = false;
     int r1 = tk.next_u32(&uid);
-    if (r1 < 0) { printf("error: unexpected lines in file\n"); return -2; }   // empty file: ratings.cc:71-75
+    if (r1 < 0) { printf("error: unexpected lines in file\n"); fflush(stdout); return -2; }   // empty file: ratings.cc:71-75
     // EOF inside the last record: fscanf returns 1 or 2 (>= 0) and the
     // reference goes on with the stale values of the missing fields
     int r2 = r1 == 1 ? tk.next_u32(&mid) : 0;
