@@ -244,6 +244,22 @@ def main():
 
     tm = D.mean_timing(min(args.steps, 64))
     ab = D.algorithmic_bytes()
+    copy_gbs = None
+    if rank == 0:
+        # context for the roofline: what a plain device-to-device copy reaches on
+        # this GPU right now (read + write bytes / time), outside the timed region
+        src = torch.empty(1 << 27, dtype=torch.float64, device=dev)        # 1 GiB
+        dst = torch.empty_like(src)
+        src.fill_(1.0)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
     if rank == 0:
         # dominant kernel of the iteration and its HBM roofline position
         kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
@@ -284,6 +300,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
+                "hbm_copy_measured_GBps": copy_gbs,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
             "replica_check": replica_check,

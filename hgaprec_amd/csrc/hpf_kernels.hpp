@@ -230,8 +230,10 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 }
 
 // long rows: S[row] = sum over its segments' partials, in segment order.
-// One wave per long row, lane = column (+64, ...); the slot loop is unrolled
-// so that 8 independent loads are in flight per lane, the adds stay in order.
+// One wave per long row; a lane owns columns c and c + 64 at once and the slot
+// loop is unrolled 16-fold, so 32 independent loads are in flight per lane
+// (the longest row -- thousands of slots for a blockbuster item -- sets the
+// kernel's duration: it is a latency chain).  The adds stay in slot order.
 __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
                                                                const double *partial, double *S, uint32_t ld,
                                                                uint32_t accumulate)
@@ -241,19 +243,23 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t r = wave; r < nrows; r += nwaves) {
     const LongRow lr = rows[r];
-    for (uint32_t c = lane; c < ld; c += 64) {
-      const double *p = partial + (size_t)lr.first_slot * ld + c;
-      double s = 0.0;
+    for (uint32_t c = lane; c < ld; c += 128) {
+      const bool two = c + 64 < ld;
+      const double *p0 = partial + (size_t)lr.first_slot * ld + c;
+      const double *p1 = two ? p0 + 64 : p0;
+      double s0 = 0.0, s1 = 0.0;
       uint32_t q = 0;
-      for (; q + 8 <= lr.nslots; q += 8) {
-        double v[8];
+      for (; q + 16 <= lr.nslots; q += 16) {
+        double v0[16], v1[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(q + j) * ld];
+        for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * ld]; v1[j] = p1[(size_t)(q + j) * ld]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
+        for (int j = 0; j < 16; ++j) { s0 += v0[j]; s1 += v1[j]; }
       }
-      for (; q < lr.nslots; ++q) s += p[(size_t)q * ld];
-      S[(size_t)lr.row * ld + c] = accumulate ? S[(size_t)lr.row * ld + c] + s : s;
+      for (; q < lr.nslots; ++q) { s0 += p0[(size_t)q * ld]; s1 += p1[(size_t)q * ld]; }
+      double *d = S + (size_t)lr.row * ld + c;
+      d[0] = accumulate ? d[0] + s0 : s0;
+      if (two) d[64] = accumulate ? d[64] + s1 : s1;
     }
   }
 }
