@@ -163,24 +163,27 @@ static inline uint32_t hash32(uint32_t k) { k *= 2654435761u; return k ^ (k >> 1
 
 void Ratings::IdMap::rehash(uint32_t cap)
 {
-  std::vector<uint32_t> ok(std::move(keys)), ov(std::move(vals)); std::vector<uint8_t> ou(std::move(used));
-  keys.assign(cap, 0); vals.assign(cap, 0); used.assign(cap, 0); cnt = 0;
-  for (size_t i = 0; i < ou.size(); ++i) if (ou[i]) put(ok[i], ov[i]);
+  std::vector<uint64_t> old(std::move(slots));
+  slots.assign(cap, 0); cnt = 0;
+  for (uint64_t e : old) if ((uint32_t)e) put((uint32_t)(e >> 32), (uint32_t)e - 1);
 }
 bool Ratings::IdMap::find(uint32_t key, uint32_t *val) const
 {
-  const uint32_t mask = (uint32_t)keys.size() - 1;
-  for (uint32_t i = hash32(key) & mask; used[i]; i = (i + 1) & mask)
-    if (keys[i] == key) { *val = vals[i]; return true; }
-  return false;
+  const uint32_t mask = (uint32_t)slots.size() - 1;
+  for (uint32_t i = hash32(key) & mask;; i = (i + 1) & mask) {
+    const uint64_t e = slots[i];
+    if (!(uint32_t)e) return false;
+    if ((uint32_t)(e >> 32) == key) { *val = (uint32_t)e - 1; return true; }
+  }
 }
 void Ratings::IdMap::put(uint32_t key, uint32_t val)
 {
-  if ((uint64_t)(cnt + 1) * 2 > keys.size()) rehash((uint32_t)keys.size() * 2);
-  const uint32_t mask = (uint32_t)keys.size() - 1;
+  if ((uint64_t)(cnt + 1) * 2 > slots.size()) rehash((uint32_t)slots.size() * 2);
+  const uint32_t mask = (uint32_t)slots.size() - 1;
   uint32_t i = hash32(key) & mask;
-  for (; used[i]; i = (i + 1) & mask) if (keys[i] == key) { vals[i] = val; return; }
-  used[i] = 1; keys[i] = key; vals[i] = val; cnt++;
+  for (; (uint32_t)slots[i]; i = (i + 1) & mask)
+    if ((uint32_t)(slots[i] >> 32) == key) { slots[i] = ((uint64_t)key << 32) | (val + 1u); return; }
+  slots[i] = ((uint64_t)key << 32) | (val + 1u); cnt++;
 }
 
 uint32_t Ratings::input_rating_class(uint32_t v) const     // ratings.hh:191-197
@@ -229,8 +232,9 @@ int Ratings::read_generic(FILE *f, HeldOut *out)
   // capacity for this pass: ratings.cc:35-36 shrinks env.n / env.m to the
   // registered counts once the training file has been read
   const uint32_t lim_n = out ? n : cap_n, lim_m = out ? m : cap_m;
-  std::vector<uint64_t> ord;                    // held-out insertion order
   bool first = true;
+  bool have_last_u = false, have_last_m = false;
+  uint32_t last_uid = 0, last_us = 0, last_mid = 0, last_ms = 0;
   while (true) {
     // while (!feof(f)) { if (fscanf(...) < 0) exit(-1); ... }
     if (!first && tk.at_eof()) break;           // the trailing "\n" directive ate the whitespace
@@ -246,8 +250,13 @@ int Ratings::read_generic(FILE *f, HeldOut *out)
       fprintf(stderr, "error: malformed line in ratings file\n");
       return -2;
     }
+    // files are usually grouped by user: remember the last successful lookup
     uint32_t us = 0, ms = 0;
-    const bool hasu = user2seq.find(uid, &us), hasm = item2seq.find(mid, &ms);
+    bool hasu, hasm;
+    if (have_last_u && uid == last_uid) { hasu = true; us = last_us; }
+    else if ((hasu = user2seq.find(uid, &us))) { have_last_u = true; last_uid = uid; last_us = us; }
+    if (have_last_m && mid == last_mid) { hasm = true; ms = last_ms; }
+    else if ((hasm = item2seq.find(mid, &ms))) { have_last_m = true; last_mid = mid; last_ms = ms; }
     if ((!hasu && n >= lim_n) || (!hasm && m >= lim_m)) continue;
     if (input_rating_class(rating) == 0) continue;
     if (!hasu) { us = n; user2seq.put(uid, us); seq2user.push_back(uid); n++; }     // ratings.hh:117-133
@@ -287,10 +296,14 @@ int Ratings::read_train(const std::string &path)
       val[(size_t)p] = binary ? 1 : (uint8_t)tr_y_[j];       // yval_t = uint8_t (env.hh:20)
     }
   }
-  std::vector<uint32_t> perm;
+  // rows with a repeated item are rare: find them with a "last user that listed
+  // this item" stamp (linear), and only those rows take the sort-based fix-up
+  std::vector<uint32_t> perm, stamp(m, 0xffffffffu);
   for (uint32_t u = 0; u < n; ++u) {
     const int64_t a = rowptr[u], b = rowptr[u + 1];
-    if (b - a < 2) continue;
+    bool dup = false;
+    for (int64_t j = a; j < b; ++j) { if (stamp[col[(size_t)j]] == u) dup = true; stamp[col[(size_t)j]] = u; }
+    if (!dup) continue;
     perm.resize((size_t)(b - a));
     std::iota(perm.begin(), perm.end(), 0u);
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return col[a + x] < col[a + y]; });

@@ -104,7 +104,8 @@ struct Ratings {
  // open-addressing id -> seq maps (std::map in the reference; only lookups
   // and insertion order matter)
   struct IdMap {
-    std::vector<uint32_t> keys, vals; std::vector<uint8_t> used; uint32_t cnt = 0;
+    // one 8-byte slot per entry (key, seq + 1; 0 = empty): a probe touches one cache line
+    std::vector<uint64_t> slots; uint32_t cnt = 0;
     IdMap() { rehash(1024); }
     void rehash(uint32_t cap);
     bool find(uint32_t key, uint32_t *val) const;
