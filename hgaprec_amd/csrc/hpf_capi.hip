@@ -46,6 +46,13 @@ struct Side {
   Seg *segs[2] = {nullptr, nullptr}; uint32_t nseg[2] = {0, 0};
   LongRow *longrows[2] = {nullptr, nullptr}; uint32_t nlong[2] = {0, 0};
   double *partial = nullptr; uint32_t npartial = 0;
+  // rows with more than HUGE_SLOTS segments are combined in two levels so that
+  // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
+  // consecutive partials are summed into partial2 (grouprows), then the group
+  // sums into S (hugerows, reading partial2)
+  LongRow *grouprows[2] = {nullptr, nullptr}; uint32_t ngroup[2] = {0, 0};
+  LongRow *hugerows[2] = {nullptr, nullptr}; uint32_t nhuge[2] = {0, 0};
+  double *partial2 = nullptr; uint32_t npartial2 = 0;
   double hot_share = 0.0; uint32_t hot_rows = 0;
   uint32_t *idx = nullptr; uint8_t *val = nullptr;
   int32_t bias_col = -1, junk_col = -1;
@@ -75,6 +82,7 @@ struct hpf_handle {
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
   uint32_t seg_max = 512;
+  uint32_t huge_slots = 256, group_slots = 64;  // two-level combine above huge_slots segments (HPF_HUGE_SLOTS)
   bool hot_force = false;               // HPF_HOT_FORCE=1: split even when the estimate says no (tests)
   uint64_t hot_bytes = 0;               // HPF_HOT_BYTES: size of the L2-resident hot set; 0 = single phase.
                                         // Measured at C2 (3.5 MiB hot set): user pass 4.3 -> 5.7 ms -- the
@@ -167,7 +175,8 @@ void free_side(Side &s, bool S_external)
   dfree(s.colsum_used); dfree(s.colsum_part);
   dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
   dfree(s.segs[0]); dfree(s.segs[1]); dfree(s.longrows[0]); dfree(s.longrows[1]);
-  dfree(s.partial); dfree(s.idx); dfree(s.val);
+  dfree(s.grouprows[0]); dfree(s.grouprows[1]); dfree(s.hugerows[0]); dfree(s.hugerows[1]);
+  dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
   s = Side();
 }
 
@@ -312,9 +321,13 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
                      const uint32_t *idx, const uint8_t *val, uint64_t nnz,
                      const int64_t *ptr_oth, uint32_t rows_oth)
 {
-  for (int p = 0; p < 2; ++p) { dfree(s.segs[p]); dfree(s.longrows[p]); s.segs[p] = nullptr; s.longrows[p] = nullptr; s.nseg[p] = s.nlong[p] = 0; }
-  dfree(s.partial); dfree(s.idx); dfree(s.val);
-  s.partial = nullptr; s.idx = nullptr; s.val = nullptr;
+  for (int p = 0; p < 2; ++p) {
+    dfree(s.segs[p]); dfree(s.longrows[p]); dfree(s.grouprows[p]); dfree(s.hugerows[p]);
+    s.segs[p] = nullptr; s.longrows[p] = s.grouprows[p] = s.hugerows[p] = nullptr;
+    s.nseg[p] = s.nlong[p] = s.ngroup[p] = s.nhuge[p] = 0;
+  }
+  dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
+  s.partial = nullptr; s.partial2 = nullptr; s.idx = nullptr; s.val = nullptr;
   s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0;
 
   // ---- hot set: the highest-degree other-side rows whose W rows fit in one L2
@@ -362,8 +375,32 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
   build_segments(start0, len0, h->seg_max, false, &np, segs[0], longs[0]);
   if (s.phases == 2) build_segments(start1, len1, h->seg_max, true, &np, segs[1], longs[1]);
   s.npartial = np;
+  // split off the very long rows (two-level combine)
+  std::vector<LongRow> groups[2], huge[2]; uint32_t np2 = 0;
+  for (int p = 0; p < 2; ++p) {
+    std::vector<LongRow> keep;
+    for (const LongRow &lr : longs[p]) {
+      if (lr.nslots <= h->huge_slots) { keep.push_back(lr); continue; }
+      LongRow top; top.row = lr.row; top.first_slot = np2; top.nslots = 0; top.pad = 0;
+      for (uint32_t q = 0; q < lr.nslots; q += h->group_slots) {
+        LongRow g; g.row = np2++; g.first_slot = lr.first_slot + q;
+        g.nslots = std::min<uint32_t>(h->group_slots, lr.nslots - q); g.pad = 0;
+        groups[p].push_back(g); top.nslots++;
+      }
+      huge[p].push_back(top);
+    }
+    longs[p].swap(keep);
+  }
+  s.npartial2 = np2;
   int rc;
   for (int p = 0; p < 2; ++p) {
+    s.ngroup[p] = (uint32_t)groups[p].size(); s.nhuge[p] = (uint32_t)huge[p].size();
+    if (s.ngroup[p]) {
+      if ((rc = dalloc(h, &s.grouprows[p], groups[p].size()))) return rc;
+      if ((rc = dalloc(h, &s.hugerows[p], huge[p].size()))) return rc;
+      HIPCHK(h, hipMemcpyAsync(s.grouprows[p], groups[p].data(), groups[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(s.hugerows[p], huge[p].data(), huge[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+    }
     s.nseg[p] = (uint32_t)segs[p].size(); s.nlong[p] = (uint32_t)longs[p].size();
     if ((rc = dalloc(h, &s.segs[p], segs[p].size()))) return rc;
     if ((rc = dalloc(h, &s.longrows[p], longs[p].size()))) return rc;
@@ -373,6 +410,7 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
       HIPCHK(h, hipMemcpyAsync(s.longrows[p], longs[p].data(), longs[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
   }
   if ((rc = dalloc(h, &s.partial, (size_t)np * h->ld))) return rc;
+  if (np2 && (rc = dalloc(h, &s.partial2, (size_t)np2 * h->ld))) return rc;
   if ((rc = dalloc(h, &s.idx, (size_t)nnz))) return rc;
   if (nnz)
     HIPCHK(h, hipMemcpyAsync(s.idx, up_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
@@ -526,10 +564,20 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
     }
     // the event separates the (last) phi kernel from the combine that follows it
     if (ph + 1 == own.phases && !h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
+    if (own.ngroup[ph]) {                       // level 1 of the very long rows: partial -> partial2
+      const uint32_t blocks = std::min<uint32_t>((own.ngroup[ph] + 3) / 4, 16384);
+      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                         own.grouprows[ph], own.ngroup[ph], own.partial, own.partial2, h->ld, 0u);
+    }
     if (own.nlong[ph]) {
       const uint32_t blocks = std::min<uint32_t>((own.nlong[ph] + 3) / 4, 16384);
       hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
                          own.longrows[ph], own.nlong[ph], own.partial, own.S, h->ld, ph);
+    }
+    if (own.nhuge[ph]) {                        // level 2: partial2 -> S
+      const uint32_t blocks = std::min<uint32_t>((own.nhuge[ph] + 3) / 4, 16384);
+      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                         own.hugerows[ph], own.nhuge[ph], own.partial2, own.S, h->ld, ph);
     }
   }
   return check_launch(h, "phi pass");
@@ -786,6 +834,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
   if (const char *e = getenv("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
   if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
+  if (const char *e = getenv("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;

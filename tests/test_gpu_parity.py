@@ -80,6 +80,28 @@ def test_power_law_long_rows_and_singletons(orc):
         assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
 
 
+@pytest.mark.parametrize("huge_slots", [8, 256])
+def test_one_user_holds_most_ratings(orc, monkeypatch, huge_slots):
+    # one user with > 50 % of all nonzeros (every item), one item
+    # rated by every user.  Its row is cut into hundreds of segments whose
+    # partial sums are combined in two levels (groups of partials, then the
+    # group sums) once it has more than HPF_HUGE_SLOTS segments.
+    monkeypatch.setenv("HPF_SEG_MAX", "16")
+    monkeypatch.setenv("HPF_HUGE_SLOTS", str(huge_slots))
+    n, m, K = 400, 3000, 12
+    M, D = _run_pair(orc, n, m, K, 2000, True, True, False, 4, seed=31,
+                     prob_kw=dict(heavy_user=True, heavy_item=True))
+    for it in range(4):
+        M.iterate(1)
+        D.iterate(1)
+    for w in compare_states(True, True):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+    hu, hi, hy = heldout_pairs(n, m, 300, seed=2)
+    so = M.heldout_sum(hu, hi, hy)
+    sd, cnt = D.heldout_ll(hu, hi, hy)
+    assert cnt == hu.size and abs(sd - so) / hu.size < 1e-9
+
+
 def test_rating_wrapped_to_zero_is_unscaled(orc):
     # rating 256 is stored as uint8 0 by the reference; "if (y > 1) scale" then
     # leaves phi unscaled (hgaprec.cc:1355)
