@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
 // digamma for x > 0, in the split form the sweep needs:
 //     psi(x) = log(xs) - corr ,   exp(psi(x)) = xs * exp(-corr)
 // x < 10 is shifted by exactly 10 with psi(x) = psi(x+10) - P'(x)/P(x),
-// P(x) = prod_{j<10}(x+j) (one division instead of ten), then the asymptotic
+// P(x) = prod_{j<10}(x+j) (one reciprocal instead of ten), then the asymptotic
 // series (A&S 6.3.18) through x^-14 at xs >= 10.  Stands where the reference
 // calls gsl_sf_psi (gpbase.hh:260).  |err| <~ 4e-15 abs on [1e-30, inf).
 // ---------------------------------------------------------------------
@@ -287,10 +287,17 @@ __device__ __forceinline__ double fast_rcp(double x)
 
 __device__ __forceinline__ PsiParts psi_parts(double x)
 {
+  // sum_{j<10} 1/(x+j): the terms pair up, 1/(x+j) + 1/(x+9-j) = (2x+9)/(t + j(9-j))
+  // with t = x(x+9), so P(x) = Q(t) = prod_{j<5}(t + c_j), c = 0, 8, 14, 18, 20, and
+  // the sum is (2x+9) Q'(t)/Q(t): half the multiplies of the direct product
   double p = 1.0, dp = 0.0;
   if (x < 10.0) {
+    const double t = x * (x + 9.0);
+    const double cj[5] = {0.0, 8.0, 14.0, 18.0, 20.0};
 #pragma unroll
-    for (int j = 0; j < 10; ++j) { dp = fma(dp, x, p); p *= x; x += 1.0; }
+    for (int j = 0; j < 5; ++j) { const double f = t + cj[j]; dp = fma(dp, f, p); p *= f; }
+    dp *= fma(2.0, x, 9.0);
+    x += 10.0;
   }
   const double xi = fast_rcp(x), x2 = xi * xi;
   double s = 1.0 / 12.0;
@@ -383,9 +390,10 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
           // GPBase::make_nonzero, gpbase.hh:27-44
           sh = (sh > 0.0) ? sh : 1e-30;
           rt = (rt > 0.0) ? rt : 1e-30;
-          e = sh / rt;                              // exported: IEEE division like the reference
+          const double ri = fast_rcp(rt);           // ~1 ulp; the exported E is an IEEE sh / rt
+          e = sh * ri;                              //   (materialize_es_kernel); this one feeds sums
           const PsiParts ps = psi_parts(sh);
-          w[t] = ps.xs * exp(-ps.corr) * fast_rcp(rt);   // exp(psi(shape) - log(rate))
+          w[t] = ps.xs * exp(-ps.corr) * ri;        // exp(psi(shape) - log(rate))
           if (real) { rsum += e; csum[t] += e; }
         } else if (junk) {
           w[t] = 1.0;                               // Elog 0 in the other side's bias slot
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     }
     wmax = group_max<G>(wmax);
     rsum = group_sum<G>(rsum);
-    const double inv = (wmax > 0.0) ? 1.0 / wmax : 0.0;
+    const double inv = (wmax > 0.0) ? fast_rcp(wmax) : 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const uint32_t c = g + G * t;
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 // shape = s_prior + S_raw (in place) and E = shape / rate for export, held-out
 // likelihood, ranking and ELBO: the hot loop itself only needs W and the
 // column sums, so the sweep does not spend 16 B/element of writes on them.
-// Same expressions as the sweep => the same bits the sweep summed.
+// (The sweep's own E, which only feeds the column / row sums, is sh * rcp(rate): <= 1 ulp apart.)
 __global__ void materialize_es_kernel(double *S, double *E, const double *prior_used,
                                       const double *colsum_used, uint32_t rows, uint32_t ld, uint32_t K,
                                       int32_t bias_col, double bias_rate_add, double s_prior,
