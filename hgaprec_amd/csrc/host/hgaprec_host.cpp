@@ -11,6 +11,8 @@
 #include <ctime>
 #include <numeric>
 #include <sstream>
+#include <thread>
+#include <functional>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -684,29 +686,63 @@ struct BufWriter {
 };
 }  // namespace
 
+// rows [r0, r1) of the matrix as text into out (grown when needed, never shrunk); *len = bytes
+static void format_rows(const double *a, uint32_t r0, uint32_t r1, uint32_t cols,
+                        const uint32_t *seq2id, uint32_t nids, uint32_t row0, std::vector<char> &out, size_t *len)
+{
+  size_t pos = 0;
+  for (uint32_t i = r0; i < r1; ++i) {
+    const uint32_t seq = i + row0;
+    const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
+    if (out.size() < pos + 32) out.resize(std::max(out.size() * 2, pos + ((size_t)1 << 16)));
+    char *o = out.data() + pos, *o0 = o;
+    o = put_u32(o, seq); *o++ = '\t';
+    o = put_u32(o, id); *o++ = '\t';
+    pos += (size_t)(o - o0);
+    for (uint32_t k = 0; k < cols; ++k) {
+      if (out.size() < pos + 420) out.resize(std::max(out.size() * 2, pos + ((size_t)1 << 16)));
+      o = out.data() + pos; o0 = o;
+      o += format_fixed8(a[(size_t)i * cols + k], o);
+      *o++ = (k == cols - 1) ? '\n' : '\t';
+      pos += (size_t)(o - o0);
+    }
+  }
+  *len = pos;
+}
+
+// Formatting is the cost of a save (330 M numbers at C2): above ~2 M numbers the
+// row blocks are formatted by all host threads, a wave of blocks at a time, and
+// written in order -- the bytes are those of the serial writer.
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
                 const uint32_t *seq2id, uint32_t nids, uint32_t row0)
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
-  BufWriter w(tf);
-  for (uint32_t i = 0; i < rows; ++i) {
-    const uint32_t seq = i + row0;
-    const uint32_t id = (seq2id && seq < nids) ? seq2id[seq] : seq;
-    char *o = w.room(32), *o0 = o;
-    o = put_u32(o, seq); *o++ = '\t';
-    o = put_u32(o, id); *o++ = '\t';
-    w.advance((size_t)(o - o0));
-    for (uint32_t k = 0; k < cols; ++k) {
-      o = w.room(420); o0 = o;
-      o += format_fixed8(a[(size_t)i * cols + k], o);
-      *o++ = (k == cols - 1) ? '\n' : '\t';
-      w.advance((size_t)(o - o0));
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = getenv("HGAPREC_SAVE_THREADS")) nt = (unsigned)atoi(e);
+  if (nt < 1) nt = 1;
+  if (nt > 64) nt = 64;
+  if ((uint64_t)rows * cols < (2u << 20)) nt = 1;
+  const uint32_t blk = std::max<uint32_t>(1, (uint32_t)((1u << 18) / std::max<uint32_t>(cols, 1)));   // ~256 K numbers
+  std::vector<std::vector<char>> bufs(nt);
+  std::vector<size_t> lens(nt, 0);
+  bool ok = true;
+  for (uint32_t r = 0; r < rows && ok; r += blk * nt) {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+      const uint32_t r0 = r + t * blk;
+      lens[t] = 0;
+      if (r0 >= rows) continue;
+      const uint32_t r1 = (uint32_t)std::min<uint64_t>(rows, (uint64_t)r0 + blk);
+      if (nt == 1) format_rows(a, r0, r1, cols, seq2id, nids, row0, bufs[t], &lens[t]);
+      else th.emplace_back(format_rows, a, r0, r1, cols, seq2id, nids, row0, std::ref(bufs[t]), &lens[t]);
     }
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < nt && ok; ++t)
+      if (lens[t]) ok = fwrite(bufs[t].data(), 1, lens[t], tf) == lens[t];
   }
-  w.flush();
-  fclose(tf);
-  return 0;
+  ok = (fclose(tf) == 0) && ok;
+  return ok ? 0 : -1;
 }
 
 int save_vector(const std::string &path, const double *a, uint32_t rows,

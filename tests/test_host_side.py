@@ -254,6 +254,27 @@ def test_writers_match_reference_format(tmp_path):
 
 
 # ----------------------------------------------------------- stop rule -------
+def test_parallel_matrix_writer_is_byte_identical(tmp_path, monkeypatch):
+    # large matrices are formatted by several threads, a wave of row blocks at a
+    # time; the file must be the serial writer's, byte for byte
+    rng = np.random.default_rng(4)
+    a = rng.gamma(0.3, 2.0, size=(30011, 83))
+    a[::53, 7] = 0.0
+    a[11, 3] = 1e-9
+    a[12, 4] = 98765.4321
+    ids = rng.permutation(10 * a.shape[0])[: a.shape[0]].astype(np.uint32)
+    out = {}
+    for nt in ("1", "3", "8"):
+        monkeypatch.setenv("HGAPREC_SAVE_THREADS", nt)
+        assert hostlib.save_matrix(tmp_path / f"m{nt}.tsv", a, ids) == 0
+        out[nt] = (tmp_path / f"m{nt}.tsv").read_bytes()
+    assert out["1"] == out["3"] == out["8"]
+    lines = out["8"].decode().splitlines()
+    assert len(lines) == a.shape[0]
+    for r in (0, 11, 12, 53, a.shape[0] - 1):
+        assert lines[r] == "\t".join([str(r), str(ids[r])] + ["%.8f" % v for v in a[r]])
+
+
 def test_stop_rule():
     # hgaprec.cc:1476-1492: nothing before iter > 30; why=0 on a tiny relative gain,
     # why=1 after three consecutive decreases (nh > 2)
