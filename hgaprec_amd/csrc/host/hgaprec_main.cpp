@@ -172,12 +172,10 @@ struct Driver {
     int rc;
     if (comm.world == 1) { if ((rc = hpf_iterate(h, 1))) die("hpf_iterate", rc); return; }
     if (use_rccl) {
-      // the all-reduce of the item sums (m*ld doubles) overlaps the user-major
-      // pass and the user sweep; the [ld] tail follows
-      if ((rc = hpf_iterate_local_items(h))) die("hpf_iterate_local_items", rc);
-      if ((rc = hpf_allreduce_items_begin(h))) die("hpf_allreduce_items_begin", rc);
-      if ((rc = hpf_iterate_local_users(h))) die("hpf_iterate_local_users", rc);
-      if ((rc = hpf_allreduce_exchange(h))) die("hpf_allreduce_exchange", rc);
+      // item pass, all-reduce of the item sums (m*ld doubles) on a second stream
+      // underneath the user pass and the user sweep, [ld] tail, item sweep
+      if ((rc = hpf_iterate(h, 1))) die("hpf_iterate", rc);
+      return;
     } else {
       if ((rc = hpf_iterate_local(h))) die("hpf_iterate_local", rc);
       void *p; size_t cnt;

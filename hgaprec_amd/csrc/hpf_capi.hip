@@ -1193,7 +1193,19 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
 int hpf_iterate(hpf_handle *h, int n_iters)
 {
   if (!h || n_iters < 0) return HPF_ERR_INVALID;
-  if (h->cfg.n_ranks != 1) { h->err = "hpf_iterate needs n_ranks == 1; use iterate_local/global"; return HPF_ERR_INVALID; }
+  if (h->cfg.n_ranks != 1) {
+    // several ranks: whole iterations only when the library owns the exchange
+    if (!h->comm) { h->err = "hpf_iterate with n_ranks > 1 needs hpf_comm_init (or use iterate_local / your all-reduce / iterate_global)"; return HPF_ERR_INVALID; }
+    for (int t = 0; t < n_iters; ++t) {
+      int rc;
+      if ((rc = phi_items(h))) return rc;
+      if ((rc = hpf_allreduce_items_begin(h))) return rc;
+      if ((rc = iterate_local_users(h))) return rc;
+      if ((rc = hpf_allreduce_exchange(h))) return rc;
+      if ((rc = iterate_global(h))) return rc;
+    }
+    return HPF_OK;
+  }
   if (n_iters > 0 && want_graph(h)) return iterate_graph(h, n_iters);
   for (int t = 0; t < n_iters; ++t) {
     int rc;

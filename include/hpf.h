@@ -135,7 +135,9 @@ int  hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count);
 
 /* replaces: n_iters passes of steps A-F of HGAPRec::vb_hier
  * (hgaprec.cc:1340-1414), or of vb (927-956) / vb_bias (1226-1272) without
- * -hier.  n_ranks must be 1.  Asynchronous on the handle's stream.
+ * -hier.  With n_ranks > 1 it needs hpf_comm_init and runs the overlapped
+ * exchange (see below) itself; every rank must make the same call.
+ * Asynchronous on the handle's stream.
  * Launch-bound problems (nnz <= 4 Mi, or HPF_GRAPH=1; HPF_GRAPH=0 disables)
  * replay one captured iteration as a hipGraph: same kernels in the same
  * order, identical bits; such iterations report only iteration_ms in

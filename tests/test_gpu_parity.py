@@ -377,6 +377,9 @@ def test_unsupported_and_invalid_inputs_fail_loudly():
         D.elbo()
     with pytest.raises(HpfError):
         D.heldout_ll(np.array([9], np.uint32), np.array([0], np.uint32), np.array([1], np.int32))
+    D2 = Hpf(10, 10, 4, n_ranks=2, rank=0, n_users_total=20)
+    with pytest.raises(HpfError, match="hpf_comm_init"):
+        D2.iterate(1)                            # several ranks, but nobody owns the exchange
 
 
 def test_single_user_and_no_nonzeros(orc):
