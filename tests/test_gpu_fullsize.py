@@ -117,3 +117,96 @@ def test_c2_repeat_runs_are_bit_identical_and_shards_agree(c2):
         assert np.max(np.abs(got - te[a:b]) / te[a:b]) < 1e-10
         assert np.max(np.abs(S.get_state("BETA_E") - be) / be) < 1e-10
         S.close()
+
+
+def test_c4_bias_k200_properties():
+    """BASELINE config C4 at full size (480 189 x 17 770, ~9.3e7 nnz, K=200,
+    -hier -bias): with the bias slots every nonzero's phi still sums to
+    max(y, 1) over K + 2 slots; the user side receives slots 0..K-1 and K, the
+    item side 0..K-1 and K+1 (hgaprec.cc:1357-1366)."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    cfg = dict(synth.CONFIGS["C4"])
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev)
+    D = Hpf(n, m, K, hier=True, bias=True)
+    D.upload_csr(rowptr, col, val)
+    st = synth.initial_state(n, K, 1, dev)
+    D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, 2, dev)
+    D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    beta_E0 = st["E"]
+    xi0 = synth.initial_state(n, K, 3, dev, prior_v=K)["E"]
+    D.set_state("XI_E", xi0)
+    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    st = synth.initial_state(n, K, 5, dev, prior_v=m)
+    D.set_state("UBIAS_E", st["E"]); D.set_state("UBIAS_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, 6, dev, prior_v=n)
+    D.set_state("IBIAS_E", st["E"]); D.set_state("IBIAS_ELOG", st["Elog"])
+    del st
+    torch.cuda.empty_cache()
+    D.iterate(1)
+    ts, bs = D.get_state("THETA_SHAPE"), D.get_state("BETA_SHAPE")
+    us, is_ = D.get_state("UBIAS_SHAPE"), D.get_state("IBIAS_SHAPE")
+    w = np.maximum(val, 1).astype(np.float64)
+    mass = float(w.sum())
+    common = (ts - 0.3).sum()
+    assert abs(common - (bs - 0.3).sum()) / mass < 1e-11              # slots 0..K-1 reach both sides
+    assert abs(common + (us - 0.3).sum() + (is_ - 0.3).sum() - mass) / mass < 1e-11
+    # per item: slots 0..K-1 plus the item-bias slot, plus the user-bias mass that went to its raters
+    assert np.all(us > 0.3) and np.all(is_ > 0.3)
+    # rates: theta as in -hier, biases constant (hgaprec.cc:1389,1393)
+    tr = D.get_state("THETA_RATE")
+    want = xi0[:, None] + beta_E0.sum(0)[None, :]
+    assert np.max(np.abs(tr - want) / want) < 1e-12
+    ue, ie = D.get_state("UBIAS_E"), D.get_state("IBIAS_E")
+    assert np.max(np.abs(ue - us / (0.3 + m)) / ue) < 1e-15
+    assert np.max(np.abs(ie - is_ / (0.3 + n)) / ie) < 1e-15
+    # a second iteration keeps the books balanced too (new W, long item rows)
+    D.iterate(1)
+    ts2 = D.get_state("THETA_SHAPE")
+    tot = (ts2 - 0.3).sum() + (D.get_state("UBIAS_SHAPE") - 0.3).sum() + (D.get_state("IBIAS_SHAPE") - 0.3).sum()
+    assert abs(tot - mass) / mass < 1e-11
+    D.close()
+
+
+def test_c5_shape_binary_k50_properties():
+    """BASELINE config C5's shape (-hier -binary-data, K=50, heavy-tailed
+    degrees alpha = 0.9 / 1.1) at 1/50 of its size (one GPU's share of a
+    50-GPU run: 1M x 40K, ~1e8 nnz): every nonzero is a 1, phi sums to 1."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    cfg = dict(synth.CONFIGS["C5"])
+    n, m, nnz, K = cfg["n"] // 50, cfg["m"] // 50, cfg["nnz"] // 50, cfg["K"]
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate(n, m, nnz, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev,
+                                      binary=True)
+    assert val is None
+    D = Hpf(n, m, K, hier=True, binary=True)
+    D.upload_csr(rowptr, col, None)
+    st = synth.initial_state(n, K, 1, dev)
+    D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, 2, dev)
+    D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    D.set_state("XI_E", synth.initial_state(n, K, 3, dev, prior_v=K)["E"])
+    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    del st
+    torch.cuda.empty_cache()
+    D.iterate(2)
+    ts, bs = D.get_state("THETA_SHAPE"), D.get_state("BETA_SHAPE")
+    mass = float(rowptr[-1])
+    assert abs((ts - 0.3).sum() - mass) / mass < 1e-11
+    assert abs((bs - 0.3).sum() - mass) / mass < 1e-11
+    deg_u = np.diff(rowptr).astype(np.float64)
+    assert np.max(np.abs((ts - 0.3).sum(1) - deg_u) / np.maximum(deg_u, 1.0)) < 1e-11
+    deg_i = np.bincount(col, minlength=m).astype(np.float64)
+    assert np.max(np.abs((bs - 0.3).sum(1) - deg_i) / np.maximum(deg_i, 1.0)) < 1e-11
+    # held-out likelihood in its binary form: log(1 - exp(-s)) per pair, finite and negative
+    hu = np.arange(0, n, max(1, n // 5000), dtype=np.uint32)
+    hi = (hu.astype(np.uint64) * 7919 % m).astype(np.uint32)
+    s, c = D.heldout_ll(hu, hi, np.ones(hu.size, np.int32))
+    assert c == hu.size and np.isfinite(s) and s < 0
+    D.close()
