@@ -27,6 +27,9 @@ CONFIGS = {
 }
 
 
+CHUNK_DRAWS = 1_500_000_000
+
+
 def _degrees(n, m, nnz, alpha_u, gen, device):
     """power-law user degrees d_u ~ (rank+1)^-alpha_u, 1 <= d_u <= m/2,
     sum(d) = nnz (when the caps allow), ranks randomly permuted"""
@@ -76,31 +79,45 @@ def generate(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=F
     cdf = torch.cumsum(p / p.sum(), 0)
     iperm = torch.randperm(m, generator=igen, device=device)
 
-    users = torch.arange(n, device=device, dtype=torch.int64)
-    keys = torch.empty(0, dtype=torch.int64, device=device)
-    need = d.clone()
-    for _ in range(topup_rounds):
-        tot = int(need.sum())
-        if tot == 0:
-            break
-        u = torch.repeat_interleave(users, need)
-        r = torch.rand(tot, generator=gen, device=device, dtype=torch.float64)
-        it = iperm[torch.searchsorted(cdf, r).clamp(max=m - 1)]
-        keys = torch.unique(torch.cat([keys, u * m + it]))
-        have = torch.bincount(keys // m, minlength=n)
-        need = (d - have).clamp(min=0)
-    u = keys // m
+    # users are processed in contiguous chunks of at most CHUNK_DRAWS draws (the
+    # device sort behind torch.unique takes < 2^31 keys); one chunk -- every
+    # configuration up to C3's 1e9 nonzeros -- is the unchunked algorithm
+    cum = torch.cumsum(d, 0)
+    bounds = [0]
+    while bounds[-1] < n:
+        base = int(cum[bounds[-1] - 1]) if bounds[-1] > 0 else 0
+        nxt = int(torch.searchsorted(cum, torch.tensor(base + CHUNK_DRAWS, device=device), right=True))
+        bounds.append(min(n, max(nxt, bounds[-1] + 1)))
+    counts = torch.zeros(n, dtype=torch.int64, device=device)
+    cols, vals = [], []
+    pr = torch.tensor(RATING_P, dtype=torch.float64, device=device)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        users = torch.arange(a, b, device=device, dtype=torch.int64)
+        keys = torch.empty(0, dtype=torch.int64, device=device)
+        dc = d[a:b]
+        need = dc.clone()
+        for _ in range(topup_rounds):
+            tot = int(need.sum())
+            if tot == 0:
+                break
+            u = torch.repeat_interleave(users, need)
+            r = torch.rand(tot, generator=gen, device=device, dtype=torch.float64)
+            it = iperm[torch.searchsorted(cdf, r).clamp(max=m - 1)]
+            keys = torch.unique(torch.cat([keys, u * m + it]))
+            del u, r, it
+            have = torch.bincount(keys // m - a, minlength=b - a)
+            need = (dc - have).clamp(min=0)
+        counts[a:b] = torch.bincount(keys // m - a, minlength=b - a)
+        cols.append((keys % m).to(torch.int32).cpu().numpy().view(np.uint32))
+        if not binary:
+            vals.append((torch.multinomial(pr, keys.numel(), replacement=True, generator=gen) + 1)
+                        .to(torch.uint8).cpu().numpy())
+        del keys
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
-    rowptr[1:] = torch.cumsum(torch.bincount(u, minlength=n), 0)
-    col = (keys % m).to(torch.int32)
-    if binary:
-        val = None
-    else:
-        pr = torch.tensor(RATING_P, dtype=torch.float64, device=device)
-        val = (torch.multinomial(pr, keys.numel(), replacement=True, generator=gen) + 1).to(torch.uint8)
+    rowptr[1:] = torch.cumsum(counts, 0)
     rp = rowptr.cpu().numpy()
-    c = col.cpu().numpy().view(np.uint32)
-    v = None if val is None else val.cpu().numpy()
+    c = cols[0] if len(cols) == 1 else np.concatenate(cols)
+    v = None if binary else (vals[0] if len(vals) == 1 else np.concatenate(vals))
     return rp, c, v
 
 

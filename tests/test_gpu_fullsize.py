@@ -210,3 +210,37 @@ def test_c5_shape_binary_k50_properties():
     s, c = D.heldout_ll(hu, hi, np.ones(hu.size, np.int32))
     assert c == hu.size and np.isfinite(s) and s < 0
     D.close()
+
+
+def test_more_than_2_31_nonzeros():
+    """64-bit indexing end to end: 4M users x 200K items with ~2.4e9 nonzeros
+    (-binary-data, K=4 keeps the state small).  Per-user and per-item mass must
+    equal the degrees -- any 32-bit wrap in the work lists, the CSC build or the
+    kernels' nonzero offsets would break it."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    n, m, nnz, K = 4_000_000, 200_000, 2_500_000_000, 4
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate(n, m, nnz, 0.4, 0.7, seed=77, device=dev, binary=True)
+    torch.cuda.empty_cache()
+    assert int(rowptr[-1]) > 2**31 and val is None
+    D = Hpf(n, m, K, hier=True, binary=True)
+    D.upload_csr(rowptr, col, None)
+    st = synth.initial_state(n, K, 1, dev)
+    D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
+    st = synth.initial_state(m, K, 2, dev)
+    D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    D.set_state("XI_E", synth.initial_state(n, K, 3, dev, prior_v=K)["E"])
+    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    D.iterate(2)
+    ts, bs = D.get_state("THETA_SHAPE"), D.get_state("BETA_SHAPE")
+    deg_u = np.diff(rowptr).astype(np.float64)
+    assert np.max(np.abs((ts - 0.3).sum(1) - deg_u) / np.maximum(deg_u, 1.0)) < 1e-11
+    deg_i = np.zeros(m, np.float64)
+    step = 1 << 28
+    for a in range(0, col.size, step):                      # bincount in slices: bounded host memory
+        deg_i += np.bincount(col[a:a + step], minlength=m)
+    assert np.max(np.abs((bs - 0.3).sum(1) - deg_i) / np.maximum(deg_i, 1.0)) < 1e-11
+    assert abs((ts - 0.3).sum() - float(rowptr[-1])) / float(rowptr[-1]) < 1e-11
+    D.close()
