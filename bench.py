@@ -242,6 +242,21 @@ def main():
         replica_check = "ok" if bool(torch.equal(hi, lo)) and bool(torch.isfinite(hi).all()) else "MISMATCH"
         del be
 
+    # the timed iterations did the work: every nonzero's phi sums to max(y, 1), so
+    # the shape rows of this rank's users must hold exactly that mass (+ priors)
+    self_check = None
+    if n_loc * K <= 200_000_000:
+        ts = D.get_state("THETA_SHAPE")
+        got = float((ts - 0.3).sum())
+        if cfg["bias"]:
+            got += float((D.get_state("UBIAS_SHAPE") - 0.3).sum())
+        want_k = float(nnz_loc) if val is None else float(np.maximum(val, 1).astype(np.float64).sum())
+        del ts
+        if cfg["bias"]:
+            # the item-bias slot's share went to the items: bound instead of equality
+            self_check = {"user_side_mass_fraction": got / want_k, "ok": bool(0.0 < got <= want_k * (1 + 1e-9))}
+        else:
+            self_check = {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
     tm = D.mean_timing(min(args.steps, 64))
     ab = D.algorithmic_bytes()
     copy_gbs = None
@@ -303,7 +318,7 @@ def main():
                 "hbm_copy_measured_GBps": copy_gbs,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
-            "replica_check": replica_check,
+            "replica_check": replica_check, "self_check": self_check,
             "iteration_algorithmic_GBps": (ab["phi_user"] + ab["phi_item"] + ab["rows"]) / (dt / args.steps) / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:
