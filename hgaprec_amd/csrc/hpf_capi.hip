@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace hpf;
@@ -1017,24 +1018,55 @@ int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, co
   const uint64_t nnz = (uint64_t)rowptr[n];
   if (nnz && !col) return HPF_ERR_INVALID;
   // item-major view: counting sort by item keeps users ascending inside an
-  // item, i.e. the order in which the reference's serial loop reaches them
+  // item, i.e. the order in which the reference's serial loop reaches them.
+  // Host threads each take a contiguous user range of ~nnz/T nonzeros: private
+  // histograms, then offsets = colptr[item] + (count in the earlier ranges), then
+  // a private scatter -- the result is the serial counting sort's, bit for bit.
+  unsigned T = std::thread::hardware_concurrency();
+  if (const char *e = getenv("HPF_UPLOAD_THREADS")) T = (unsigned)atoi(e);
+  T = std::max(1u, std::min(T, 64u));
+  if (nnz < (4u << 20)) T = 1;
+  while (T > 1 && (uint64_t)T * m > (1ull << 30)) T /= 2;          // <= 4 GiB of counters
+  std::vector<uint32_t> ucut(T + 1, n);
+  ucut[0] = 0;
+  for (unsigned t = 1; t < T; ++t)
+    ucut[t] = (uint32_t)(std::lower_bound(rowptr, rowptr + n + 1, (int64_t)(nnz / T * t)) - rowptr);
+  for (unsigned t = 1; t <= T; ++t) ucut[t] = std::max(ucut[t], ucut[t - 1]);
+  std::vector<std::vector<uint32_t>> cnt(T);
+  std::vector<int> bad(T, 0);
+  auto run = [&](auto &&fn) {
+    if (T == 1) { fn(0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
+    for (auto &x : th) x.join();
+  };
+  run([&](unsigned t) {
+    std::vector<uint32_t> &c = cnt[t];
+    c.assign(m, 0);
+    for (int64_t j = rowptr[ucut[t]]; j < rowptr[ucut[t + 1]]; ++j) {
+      if (col[j] >= m) { bad[t] = 1; return; }
+      c[col[j]]++;
+    }
+  });
+  for (unsigned t = 0; t < T; ++t) if (bad[t]) { h->err = "item index out of range"; return HPF_ERR_INVALID; }
   std::vector<int64_t> colptr((size_t)m + 1, 0);
-  for (uint64_t j = 0; j < nnz; ++j) {
-    if (col[j] >= m) { h->err = "item index out of range"; return HPF_ERR_INVALID; }
-    colptr[(size_t)col[j] + 1]++;
+  for (uint32_t i = 0; i < m; ++i) {
+    uint32_t before = 0;
+    for (unsigned t = 0; t < T; ++t) { const uint32_t c = cnt[t][i]; cnt[t][i] = before; before += c; }
+    colptr[i + 1] = colptr[i] + before;
   }
-  for (uint32_t i = 0; i < m; ++i) colptr[i + 1] += colptr[i];
   std::vector<uint32_t> cuser((size_t)nnz);
   std::vector<uint8_t> cval(val ? (size_t)nnz : 0);
-  {
-    std::vector<int64_t> next(colptr.begin(), colptr.end() - 1);
-    for (uint32_t u = 0; u < n; ++u)
+  run([&](unsigned t) {
+    std::vector<uint32_t> &rel = cnt[t];
+    for (uint32_t u = ucut[t]; u < ucut[t + 1]; ++u)
       for (int64_t j = rowptr[u]; j < rowptr[u + 1]; ++j) {
-        const int64_t p = next[col[j]]++;
+        const int64_t p = colptr[col[j]] + rel[col[j]]++;
         cuser[(size_t)p] = u;
         if (val) cval[(size_t)p] = val[j];
       }
-  }
+  });
+  cnt.clear();
   int rc;
   if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz, colptr.data(), m))) return rc;
   if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz, rowptr, n))) return rc;
