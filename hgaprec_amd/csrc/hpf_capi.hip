@@ -1304,18 +1304,41 @@ int hpf_elbo(hpf_handle *h, double *out)
   int rc;
   if ((rc = refresh_elog(h, h->u))) return rc;
   if ((rc = refresh_elog(h, h->it))) return rc;
-  const uint32_t nb_nnz = (uint32_t)std::min<uint64_t>((h->nnz + 15) / 16, 8192);
+  // per-nonzero term: the user-major work list(s) of the phi pass, one wave per segment
+  const uint32_t nb_nnz = (uint32_t)std::min<uint64_t>(((uint64_t)h->u.nseg[0] + h->u.nseg[1] + 3) / 4 + 1, 16384);
   const uint32_t nb_g = 1024;
-  double *part = nullptr, *rowptr_dev = nullptr; (void)rowptr_dev;
-  const size_t npart = (size_t)std::max<uint32_t>(nb_nnz, 1) + 2 * nb_g;
+  double *part = nullptr, *Mt = nullptr, *Mb = nullptr;
+  const size_t npart = (size_t)2 * nb_nnz + 2 * nb_g;
   if ((rc = dalloc(h, &part, npart))) return rc;
   std::vector<double> hp(npart, 0.0);
   do {
-    if (h->nnz) {
+    // fp64 W: logsumexp from the hot loop's W and the row maxima of Elog (no exp per
+    // element); the f32-stored W is not precise enough for that, it takes the Elog form
+    const bool from_w = !h->w32 && h->nnz;
+    if (from_w) {
+      if ((rc = prepare_derived(h))) break;                  // W follows a set_state(ELOG), if any
+      if ((rc = dalloc(h, &Mt, h->u.rows)) || (rc = dalloc(h, &Mb, h->it.rows))) break;
+      hipLaunchKernelGGL(rowmax_elog_kernel, dim3((h->u.rows + 255) / 256), dim3(256), 0, h->stream,
+                         h->u.L, Mt, h->u.rows, h->ld, h->K, h->u.bias_col, h->u.junk_col);
+      hipLaunchKernelGGL(rowmax_elog_kernel, dim3((h->it.rows + 255) / 256), dim3(256), 0, h->stream,
+                         h->it.L, Mb, h->it.rows, h->ld, h->K, h->it.bias_col, h->it.junk_col);
+    }
+    for (uint32_t ph = 0; ph < h->u.phases && from_w; ++ph) {
+      if (!h->u.nseg[ph]) continue;
+      ElboNnzWArgs a;
+      a.segs = h->u.segs[ph]; a.nseg = h->u.nseg[ph]; a.col = h->u.idx; a.val = h->u.val;
+      a.Wt = (const double *)h->u.W; a.Wb = (const double *)h->it.W; a.Et = h->u.E; a.Eb = h->it.E;
+      a.Mt = Mt; a.Mb = Mb;
+      a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K;
+      a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
+      hipLaunchKernelGGL(elbo_nnz_w_kernel, dim3(nb_nnz), dim3(256), 0, h->stream, a);
+    }
+    for (uint32_t ph = 0; ph < h->u.phases && h->nnz && !from_w; ++ph) {
+      if (!h->u.nseg[ph]) continue;
       ElboNnzArgs a;
-      a.rowptr = h->rowptr_dev; a.col = h->u.idx; a.val = h->u.val;
+      a.segs = h->u.segs[ph]; a.nseg = h->u.nseg[ph]; a.col = h->u.idx; a.val = h->u.val;
       a.Lt = h->u.L; a.Lb = h->it.L; a.Et = h->u.E; a.Eb = h->it.E;
-      a.partial = part; a.nnz = h->nnz; a.n = h->u.rows; a.ld = h->ld; a.K = h->K; a.C = h->C;
+      a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K; a.C = h->C;
       a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
       hipLaunchKernelGGL(elbo_nnz_kernel, dim3(nb_nnz), dim3(256), 0, h->stream, a);
     }
@@ -1328,7 +1351,7 @@ int hpf_elbo(hpf_handle *h, double *out)
       ElboGammaArgs g;
       g.S = s.S; g.E = s.E; g.L = s.L; g.prior_used = s.prior_used; g.prior_elog_used = s.prior_elog_used;
       g.colsum_used = s.colsum_used; g.prior_E = s.prior_E; g.prior_elog = s.prior_elog; g.prior_rate = s.prior_rate;
-      g.partial = part + nb_nnz + (size_t)k * nb_g; g.rows = s.rows; g.ld = h->ld; g.K = h->K;
+      g.partial = part + (size_t)2 * nb_nnz + (size_t)k * nb_g; g.rows = s.rows; g.ld = h->ld; g.K = h->K;
       g.bias_col = s.bias_col; g.bias_rate_add = s.bias_rate_add; g.s_prior = s0; g.r_prior = h->cfg.r_prior;
       g.lg_s_prior = std::lgamma(s0); g.prior_shape = ps; g.lg_prior_shape = std::lgamma(ps); g.hier = h->cfg.hier;
       hipLaunchKernelGGL(elbo_gamma_kernel, dim3(nb_g), dim3(256), 0, h->stream, g);
@@ -1341,7 +1364,7 @@ int hpf_elbo(hpf_handle *h, double *out)
     for (size_t k = 0; k < npart; ++k) s += hp[k];
     *out = s;
   } while (0);
-  dfree(part);
+  dfree(part); dfree(Mt); dfree(Mb);
   return rc;
 }
 

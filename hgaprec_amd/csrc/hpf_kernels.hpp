@@ -601,50 +601,50 @@ __global__ __launch_bounds__(256) void heldout_ll_kernel(LLArgs a)
 // y*yy*(logsumexp(x) - log yy).  One 16-lane group per nonzero; block partials.
 // ---------------------------------------------------------------------
 struct ElboNnzArgs {
-  const int64_t  *rowptr;   // user CSR row pointers (to find the user of a nonzero)
+  const Seg      *segs;     // the user-major work list of the phi pass: (row, start, len)
+  uint32_t        nseg;
   const uint32_t *col;
   const uint8_t  *val;
   const double   *Lt, *Lb, *Et, *Eb;
   double         *partial;  // [gridDim.x]
-  uint64_t        nnz;
-  uint32_t        n, ld, K, C;     // C = live columns (K or K+2)
+  uint32_t        ld, K, C; // C = live columns (K or K+2)
   int32_t         ubias_col, ibias_col;
 };
 
+// one wave per segment (its user is known: no search for the owner of a
+// nonzero), the wave's four 16-lane groups take the segment's nonzeros in turn
 __global__ __launch_bounds__(256) void elbo_nnz_kernel(ElboNnzArgs a)
 {
   constexpr int G = 16;
   __shared__ double red[256 / G];
-  const int lane = threadIdx.x & 63, g = lane % G;
+  const int lane = threadIdx.x & 63, g = lane % G, q = lane / G;
   const uint32_t grp_in_block = threadIdx.x / G;
-  const uint64_t grp = (uint64_t)blockIdx.x * (blockDim.x / G) + grp_in_block;
-  const uint64_t ngrp = (uint64_t)gridDim.x * (blockDim.x / G);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   double acc = 0.0;
-  for (uint64_t j0 = 0; j0 < a.nnz; j0 += ngrp) {
-    const uint64_t j = j0 + grp;
-    const bool ok = j < a.nnz;
-    uint32_t u = 0, it = 0; double y = 1.0;
-    if (ok) {
-      // user of nonzero j: last row with rowptr[row] <= j
-      uint32_t lo = 0, hi = a.n;
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)a.rowptr[mid] <= j) lo = mid; else hi = mid; }
-      u = lo; it = a.col[j]; y = a.val ? (double)a.val[j] : 1.0;
-    }
-    const double *lt = a.Lt + (size_t)u * a.ld, *lb = a.Lb + (size_t)it * a.ld;
-    const double *et = a.Et + (size_t)u * a.ld, *eb = a.Eb + (size_t)it * a.ld;
-    double mx = -1.0e308, dot = 0.0;
-    for (uint32_t c = g; c < a.C; c += G) mx = fmax(mx, lt[c] + lb[c]);
-    mx = group_max<G>(mx);
-    double se = 0.0;
-    for (uint32_t c = g; c < a.C; c += G) se += exp(lt[c] + lb[c] - mx);
-    for (uint32_t c = g; c < a.K; c += G) dot = fma(et[c], eb[c], dot);
-    se = group_sum<G>(se);
-    dot = group_sum<G>(dot);
-    if (ok && g == 0) {
-      const double yy = (y > 1.0) ? y : 1.0;
-      double v = y * yy * (mx + log(se) - log(yy)) - dot;
-      if (a.ubias_col >= 0) v -= et[a.ubias_col] + eb[a.ibias_col];
-      acc += v;
+  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+    const Seg sg = a.segs[s];
+    const double *lt = a.Lt + (size_t)sg.row * a.ld, *et = a.Et + (size_t)sg.row * a.ld;
+    for (uint32_t o = 0; o < sg.len; o += 64 / G) {
+      const bool ok = o + q < sg.len;
+      const int64_t j = sg.start + o + q;
+      const uint32_t it = ok ? a.col[j] : 0u;
+      const double y = (ok && a.val) ? (double)a.val[j] : 1.0;
+      const double *lb = a.Lb + (size_t)it * a.ld, *eb = a.Eb + (size_t)it * a.ld;
+      double mx = -1.0e308, dot = 0.0;
+      for (uint32_t c = g; c < a.C; c += G) mx = fmax(mx, lt[c] + lb[c]);
+      mx = group_max<G>(mx);
+      double se = 0.0;
+      for (uint32_t c = g; c < a.C; c += G) se += exp(lt[c] + lb[c] - mx);
+      for (uint32_t c = g; c < a.K; c += G) dot = fma(et[c], eb[c], dot);
+      se = group_sum<G>(se);
+      dot = group_sum<G>(dot);
+      if (ok && g == 0) {
+        const double yy = (y > 1.0) ? y : 1.0;
+        double v = y * yy * (mx + log(se) - log(yy)) - dot;
+        if (a.ubias_col >= 0) v -= et[a.ubias_col] + eb[a.ibias_col];
+        acc += v;
+      }
     }
   }
   if (g == 0) red[grp_in_block] = acc;
@@ -654,6 +654,77 @@ __global__ __launch_bounds__(256) void elbo_nnz_kernel(ElboNnzArgs a)
     for (uint32_t k = 0; k < blockDim.x / G; ++k) s += red[k];
     a.partial[blockIdx.x] = s;
   }
+}
+
+// The same term from the hot loop's own arrays: W = exp(L - M) with M = the row
+// maximum of L over the live columns (0 in the other side's bias slot), so
+//   logsumexp(x) = log(sum_k Wt[u,k] * Wb[i,k]) + Mt[u] + Mb[i]
+// -- no exp per element, one pass over the row pair instead of two.  fp64 W only.
+struct ElboNnzWArgs {
+  const Seg      *segs;
+  uint32_t        nseg;
+  const uint32_t *col;
+  const uint8_t  *val;
+  const double   *Wt, *Wb, *Et, *Eb;   // [rows x ld]
+  const double   *Mt, *Mb;             // [rows] row maxima of Elog
+  double         *partial;             // [gridDim.x]
+  uint32_t        ld, K;
+  int32_t         ubias_col, ibias_col;
+};
+
+__global__ __launch_bounds__(256) void elbo_nnz_w_kernel(ElboNnzWArgs a)
+{
+  constexpr int G = 16;
+  __shared__ double red[256 / G];
+  const int lane = threadIdx.x & 63, g = lane % G, q = lane / G;
+  const uint32_t grp_in_block = threadIdx.x / G;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  double acc = 0.0;
+  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+    const Seg sg = a.segs[s];
+    const double *wt = a.Wt + (size_t)sg.row * a.ld, *et = a.Et + (size_t)sg.row * a.ld;
+    const double mt = a.Mt[sg.row];
+    for (uint32_t o = 0; o < sg.len; o += 64 / G) {
+      const bool ok = o + q < sg.len;
+      const int64_t j = sg.start + o + q;
+      const uint32_t it = ok ? a.col[j] : 0u;
+      const double y = (ok && a.val) ? (double)a.val[j] : 1.0;
+      const double *wb = a.Wb + (size_t)it * a.ld, *eb = a.Eb + (size_t)it * a.ld;
+      double z = 0.0, dot = 0.0;
+      for (uint32_t c = g; c < a.ld; c += G) z = fma(wt[c], wb[c], z);       // padding columns hold 0
+      for (uint32_t c = g; c < a.K; c += G) dot = fma(et[c], eb[c], dot);
+      z = group_sum<G>(z);
+      dot = group_sum<G>(dot);
+      if (ok && g == 0) {
+        const double yy = (y > 1.0) ? y : 1.0;
+        double v = y * yy * (log(z) + mt + a.Mb[it] - log(yy)) - dot;
+        if (a.ubias_col >= 0) v -= et[a.ubias_col] + eb[a.ibias_col];
+        acc += v;
+      }
+    }
+  }
+  if (g == 0) red[grp_in_block] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (uint32_t k = 0; k < blockDim.x / G; ++k) s += red[k];
+    a.partial[blockIdx.x] = s;
+  }
+}
+
+// M[row] = max over the live columns of Elog (the other side's bias slot counts as 0)
+__global__ void rowmax_elog_kernel(const double *L, double *M, uint32_t rows, uint32_t ld, uint32_t K,
+                                   int32_t bias_col, int32_t junk_col)
+{
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const double *l = L + (size_t)row * ld;
+  double m = -1.0e308;
+  for (uint32_t c = 0; c < K; ++c) m = fmax(m, l[c]);
+  if (bias_col >= 0) m = fmax(m, l[bias_col]);
+  if (junk_col >= 0) m = fmax(m, 0.0);
+  M[row] = m;
 }
 
 // Gamma terms of one side (compute_elbo_term_helper, gpbase.hh:360-387,717-741)
