@@ -181,20 +181,30 @@ void free_side(Side &s, bool S_external)
   s = Side();
 }
 
-// pick (G,R[,V]) with G*R*V >= ld, R <= 8, least padding, then fewest registers
-bool choose_cfg(uint32_t ld, int V, int *G, int *R, int rmax64 = 8)
+// pick (G,R[,V]) with G*R*V >= ld, R <= 8.  Cost = padded row length, +20 % when a lane
+// group spans less than one 128-byte line per load although the row is at least two
+// lines long (K=50: (4,7,2) loses to the wider, more padded (8,4,2): user pass 2.58
+// vs 2.29 ms).  Ties (row lengths that several shapes cover exactly, e.g. K = 64,
+// 128) are decided by what the K sweep on MI355X showed: keep
+// 2..7 loads per lane in flight (R = 1 has no ILP: K=64 user pass 3.30 ms vs 2.35 ms
+// at R = 4; R = 8 costs registers), span a line, and among equals be narrow (more
+// nonzeros per wave).
+bool choose_cfg(uint32_t ld, int V, int *G, int *R, int rmax64 = 8, long *cost_out = nullptr, bool gather = true)
 {
-  int bestG = 0, bestR = 0; long bestw = -1;
+  int bestG = 0, bestR = 0; long bestc = -1; int bestp = 0;
   const int Gs[5] = {4, 8, 16, 32, 64};
   for (int gi = 0; gi < 5; ++gi) {
     const int g = Gs[gi];
     const int r = (int)((ld + (uint32_t)(g * V) - 1) / (uint32_t)(g * V));
     if (r < 1 || r > (g == 64 ? rmax64 : 8)) continue;
-    const long w = (long)g * r * V - (long)ld;
-    if (bestw < 0 || w < bestw || (w == bestw && r < bestR)) { bestw = w; bestG = g; bestR = r; }
+    const bool narrow = g * V * 8 < 128;
+    const long c = (long)g * r * V * ((gather && narrow && ld * 8 >= 256) ? 12 : 10);   // the sweep streams: padding only
+    const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (narrow ? 1 : 0);
+    if (bestc < 0 || c < bestc || (c == bestc && p < bestp)) { bestc = c; bestG = g; bestR = r; bestp = p; }
   }
-  if (bestw < 0) return false;
+  if (bestc < 0) return false;
   *G = bestG; *R = bestR;
+  if (cost_out) *cost_out = bestc;
   return true;
 }
 
@@ -804,10 +814,11 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     // Elements per load: doubles 1|2, floats 2|4.
     const int Vs = h->w32 ? 2 : 1, Vl = 2 * Vs;
     int g1 = 0, r1 = 0, g2 = 0, r2 = 0;
-    const bool ok1 = choose_cfg(h->ld, Vs, &g1, &r1), ok2 = choose_cfg(h->ld, Vl, &g2, &r2);
+    long w1 = 1L << 40, w2 = 1L << 40;
+    const bool ok1 = choose_cfg(h->ld, Vs, &g1, &r1, 8, &w1), ok2 = choose_cfg(h->ld, Vl, &g2, &r2, 8, &w2);
     if (!ok1 && !ok2) return fail(HPF_ERR_UNSUPPORTED);
-    const long w1 = ok1 ? (long)g1 * r1 * Vs - (long)h->ld : 1L << 30;
-    const long w2 = ok2 ? (long)g2 * r2 * Vl - (long)h->ld : 1L << 30;
+    if (!ok1) w1 = 1L << 40;
+    if (!ok2) w2 = 1L << 40;
     if (w2 <= w1) { h->phiG = g2; h->phiR = r2; h->phiV = Vl; }
     else { h->phiG = g1; h->phiR = r1; h->phiV = Vs; }
     if (h->w32) {
@@ -818,7 +829,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       h->phiG = g; h->phiV = 4; h->phiR = (int)((h->ld + (uint32_t)(4 * g) - 1) / (uint32_t)(4 * g));
     }
   }
-  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR, 16)) return fail(HPF_ERR_UNSUPPORTED);
+  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR, 16, nullptr, false)) return fail(HPF_ERR_UNSUPPORTED);
   if (const char *e = getenv("HPF_PHI_CFG")) {
     int g = 0, r = 0, v = 0;
     if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&
