@@ -6,15 +6,24 @@
 
 A "step" is one full CAVI iteration (phi passes + row sweeps; report steps
 excluded) over one synthetic ratings matrix that is resident in HBM before the
-timed region starts.  N=1 runs BASELINE config C2 (1M x 100K, 5e7 nnz, K=100,
--hier).  N>1 is weak scaling: every rank owns a C2-sized shard of users (its
-own 5e7 nonzeros), items are shared, and the item-side shape sums plus
-sum_u E[theta_u] go through ONE RCCL all-reduce per iteration.
+timed region starts (generated on the GPU, handed over with
+hpf_upload_csr_device / hpf_set_state_device: no PCIe inside or before `value`).
+
+  N = 1   BASELINE config C2 (1M x 100K, 5e7 nnz, K=100, -hier) on one GPU.
+  N > 1   BASELINE config C3 (10M x 1M, 1e9 nnz, K=100, -hier), STRONG scaling:
+          the same matrix whatever N is; every rank generates only its own
+          nnz-balanced user range (partition_users), items are replicated, and
+          the item-side shape sums (800 MB) + sum_u E[theta_u] go through one
+          RCCL all-reduce per iteration, started right after the item-major
+          phi pass so that it travels underneath the user-major half.
+  --weak  the round-1 mode: every rank owns a C2-sized shard (weak scaling).
+
 Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,7 +35,12 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # float4 copy measured in the same guide (79 % of spec)
+REFERENCE_PROBE = {            # the reference binary itself, survey-time probe
+    "value": 0.325e6, "unit": "rating-nonzeros/s", "cores": 1, "K": 100,
+    "what": "premgopalan/hgaprec vb_hier, ML-1M-shaped input, Xeon 2.1 GHz (SURVEY.md section 6; not this host)",
+}
 
 
 def log(*a):
@@ -61,9 +75,33 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
         "sample": f"1 CAVI iteration of oracle/liborc.so (single thread) on the first {s} users "
                   f"({nz} nonzeros) of the same matrix, all {cfg['m']} items, K={cfg['K']}",
         "seconds": dt,
+        "reference_probe": REFERENCE_PROBE,
         "all_cores": {"value": nz / dt_all, "cores": orc.omp_threads(), "seconds": dt_all,
                       "note": "same slice; step A under OpenMP (atomics on item rows), expectations parallel over rows"},
     }
+
+
+def kernels_sha():
+    h = hashlib.sha256()
+    for f in ("hpf_kernels.hpp", "hpf_capi.hip"):
+        h.update((ROOT / "hgaprec_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(config, kern):
+    """HBM-side bytes per launch from the PMC passes kept in profiles/traffic.json
+    (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md).  Only quoted when the
+    file was measured on THIS kernel source (sha of the two kernel files)."""
+    tf = ROOT / "profiles" / "traffic.json"
+    if not tf.exists():
+        return None, "no profiles/traffic.json"
+    try:
+        d = json.loads(tf.read_text())
+    except Exception:
+        return None, "profiles/traffic.json unreadable"
+    if d.get("kernels_sha") != kernels_sha():
+        return None, f"stale: measured on kernels_sha {d.get('kernels_sha')}, this build is {kernels_sha()}"
+    return d.get(f"{config}:{kern}"), f"PMC passes of {d.get('measured', '?')}"
 
 
 def main():
@@ -71,13 +109,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2")
+    ap.add_argument("--config", default=None, help="C1..C5; default C2 on one GPU, C3 on several")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: weak scaling -- every rank owns its own C2-sized user shard")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n, m, nnz (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n", type=int, default=0, help="override users (experiments)")
     ap.add_argument("--m", type=int, default=0, help="override items (experiments)")
     ap.add_argument("--nnz", type=int, default=0, help="override nonzeros (experiments)")
     ap.add_argument("--K", type=int, default=0, help="override factors (experiments)")
+    ap.add_argument("--host-handover", action="store_true",
+                    help="also time hpf_upload_csr / hpf_set_state from host buffers (PCIe-inclusive set-up; never `value`)")
     ap.add_argument("--w32", action="store_true",
                     help="EXPERIMENTAL storage mode: W kept in fp32 (arithmetic/accumulators fp64); "
                          "drifts out of the 1e-4 contract after ~30 iterations -- NOT the headline configuration")
@@ -99,6 +141,7 @@ def main():
     import torch.distributed as dist
     from hgaprec_amd import synth
     from hgaprec_amd.capi import Hpf
+    from hgaprec_amd.dist import partition_users
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,7 +183,9 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
 
-    cfg = dict(synth.CONFIGS[args.config])
+    strong = world > 1 and not args.weak
+    cname = args.config or ("C3" if strong else "C2")
+    cfg = dict(synth.CONFIGS[cname])
     if args.scale != 1.0:
         for k in ("n", "m", "nnz"):
             cfg[k] = max(64, int(cfg[k] * args.scale))
@@ -148,20 +193,48 @@ def main():
         if getattr(args, k):
             cfg[k] = getattr(args, k)
     custom = args.scale != 1.0 or args.w32 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
-    n_loc, m, K = cfg["n"], cfg["m"], cfg["K"]
+    m, K = cfg["m"], cfg["K"]
 
-    # ---- synthetic shard (generated on the GPU, handed over as host CSR)
+    # ---- synthetic shard, generated on the GPU and left there
     t0 = time.perf_counter()
-    rowptr, col, val = synth.generate(n_loc, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
-                                      seed=cfg["seed"] + 1000 * rank, device=dev,
-                                      binary=cfg["binary"], item_seed=cfg["seed"])
+    if strong:
+        # ONE matrix G(seed, n, m, nnz) for every N: the generator is a pure function of
+        # (seed, user, draw), so each rank builds exactly its user range of it
+        n_total = cfg["n"]
+        deg = synth.degrees(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["seed"], dev)
+        planned = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg, 0, out=planned[1:])
+        ua, ub = partition_users(planned.cpu().numpy(), world)[rank]
+        del planned
+        rowptr, col, val = synth.generate_device(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                                 seed=cfg["seed"], device=dev, binary=cfg["binary"],
+                                                 user_range=(ua, ub), deg=deg)
+        # every rank must have cut the same matrix the same way
+        sig = torch.stack([deg.sum(), (deg * torch.arange(1, n_total + 1, device=dev)).sum() % 1_000_000_007]).to(torch.float64)
+        del deg
+        hi_, lo_ = sig.clone(), sig.clone()
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        if not torch.equal(hi_, lo_):
+            raise SystemExit("ranks disagree on the synthetic matrix: generator is not device-independent")
+        row0, state_seed_shift = ua, 0
+    else:
+        # one C2-sized matrix per rank (weak scaling; N = 1 is plain C2)
+        n_total = cfg["n"] * world
+        ua, ub = 0, cfg["n"]
+        rowptr, col, val = synth.generate_device(cfg["n"], m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                                 seed=cfg["seed"] + 1000 * rank, device=dev,
+                                                 binary=cfg["binary"], item_seed=cfg["seed"])
+        row0, state_seed_shift = 0, 1000 * rank
+    n_loc = ub - ua
     nnz_loc = int(rowptr[-1])
     torch.cuda.synchronize()
-    log(f"[rank {rank}] generated {n_loc} x {m}, nnz={nnz_loc} in {time.perf_counter() - t0:.1f}s")
+    t_gen = time.perf_counter() - t0
+    log(f"[rank {rank}] generated users [{ua}, {ub}) x {m} items, nnz={nnz_loc} in {t_gen:.1f}s")
 
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
             device=local_rank, stream=stream.cuda_stream, n_ranks=2 if (force_dist and world == 1) else world,
-            rank=rank, n_users_total=n_loc * world, w_storage=1 if args.w32 else 0)
+            rank=rank, n_users_total=n_total, w_storage=1 if args.w32 else 0)
     xbuf = None
     if use_dist:
         xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
@@ -169,28 +242,34 @@ def main():
         ld_x = xbuf.numel() // (m + 1)                        # [m x ld | ld]
         x_items, x_tail = xbuf[: m * ld_x], xbuf[m * ld_x:]
     t0 = time.perf_counter()
-    D.upload_csr(rowptr, col, val)
+    D.upload_csr_device(rowptr, col, val)
+    D.synchronize()
     t_upload = time.perf_counter() - t0
 
-    # ---- bench-mode initial state (counter RNG; the parity path uses MT19937)
+    # ---- bench-mode initial state (counter hash; the parity path uses MT19937),
+    # a function of the GLOBAL row: shards of one problem start from one state
     t0 = time.perf_counter()
-    st = synth.initial_state(n_loc, K, cfg["seed"] + 17 + 1000 * rank, dev)
-    D.set_state("THETA_SHAPE", st["shape"]); D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
-    st = synth.initial_state(m, K, cfg["seed"] + 29, dev)
-    D.set_state("BETA_SHAPE", st["shape"]); D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
+    ss = cfg["seed"] + state_seed_shift
+
+    def put(names, st):
+        for w, k in names:
+            D.set_state_device(w, st[k])
+
+    put((("THETA_SHAPE", "shape"), ("THETA_E", "E"), ("THETA_ELOG", "Elog")),
+        synth.initial_state_device(n_loc, K, ss + 17, dev, row0=row0))
+    put((("BETA_SHAPE", "shape"), ("BETA_E", "E"), ("BETA_ELOG", "Elog")),
+        synth.initial_state_device(m, K, cfg["seed"] + 29, dev))
     if cfg["hier"]:
-        st = synth.initial_state(n_loc, K, cfg["seed"] + 31 + 1000 * rank, dev, prior_v=K)
-        D.set_state("XI_E", st["E"])
-        st = synth.initial_state(m, K, cfg["seed"] + 37, dev, prior_v=K)
-        D.set_state("ETA_E", st["E"])
+        put((("XI_E", "E"),), synth.initial_state_device(n_loc, K, ss + 31, dev, prior_v=K, row0=row0))
+        put((("ETA_E", "E"),), synth.initial_state_device(m, K, cfg["seed"] + 37, dev, prior_v=K))
     if cfg["bias"]:
-        st = synth.initial_state(n_loc, K, cfg["seed"] + 41 + 1000 * rank, dev, prior_v=m)
-        D.set_state("UBIAS_E", st["E"]); D.set_state("UBIAS_ELOG", st["Elog"]); D.set_state("UBIAS_SHAPE", st["shape"])
-        st = synth.initial_state(m, K, cfg["seed"] + 43, dev, prior_v=n_loc * world)
-        D.set_state("IBIAS_E", st["E"]); D.set_state("IBIAS_ELOG", st["Elog"]); D.set_state("IBIAS_SHAPE", st["shape"])
-    del st
+        put((("UBIAS_E", "E"), ("UBIAS_ELOG", "Elog"), ("UBIAS_SHAPE", "shape")),
+            synth.initial_state_device(n_loc, K, ss + 41, dev, prior_v=m, row0=row0))
+        put((("IBIAS_E", "E"), ("IBIAS_ELOG", "Elog"), ("IBIAS_SHAPE", "shape")),
+            synth.initial_state_device(m, K, cfg["seed"] + 43, dev, prior_v=n_total))
     torch.cuda.empty_cache()
-    log(f"[rank {rank}] upload {t_upload:.1f}s, state {time.perf_counter() - t0:.1f}s")
+    t_state = time.perf_counter() - t0
+    log(f"[rank {rank}] device hand-over: csr {t_upload:.2f}s, state {t_state:.2f}s")
 
     def step():
         if not use_dist:
@@ -199,7 +278,8 @@ def main():
             # the item shape sums (m*ld doubles) are final after the item-major phi
             # pass, which runs first: their all-reduce runs on RCCL's stream while
             # the user-major pass and the user sweep run on ours; sum_u E[theta]
-            # (ld doubles) follows in a second, tiny one
+            # (ld doubles) follows in a second, tiny one.  The item update then
+            # consumes the NEW theta sums, like hgaprec.cc:1380-1386.
             D.iterate_local_items()
             w = dist.all_reduce(x_items, async_op=True)
             D.iterate_local_users()
@@ -220,6 +300,8 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    tm = D.mean_timing(min(args.steps, 64))
+    per_rank = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -227,6 +309,13 @@ def main():
         nn = torch.tensor([nnz_loc], dtype=torch.float64, device=dev)
         dist.all_reduce(nn)
         nnz_total = int(nn.item())
+        keys = ("phi_item_ms", "combine_item_ms", "phi_user_ms", "combine_user_ms", "sweep_user_ms",
+                "exchange_wait_ms", "sweep_item_ms", "iteration_ms")
+        mine = torch.tensor([float(nnz_loc), float(n_loc)] + [tm[k] for k in keys], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=r, nnz=int(v[0]), users=int(v[1]), **{k: round(float(x), 3) for k, x in zip(keys, v[2:])})
+                    for r, v in enumerate(allr)]
     else:
         nnz_total = nnz_loc
 
@@ -234,8 +323,8 @@ def main():
     if use_dist:
         # every rank must hold bit-identical item-side state after the same
         # all-reduced sums: a cheap end-of-run guard against an ordering race
-        be = D.get_state("BETA_E")
-        cs = torch.tensor([float(be.sum()), float(np.abs(be).max())], dtype=torch.float64, device=dev)
+        be = D.get_state_device("BETA_E", dev)
+        cs = torch.stack([be.sum(), be.abs().max()])
         hi, lo = cs.clone(), cs.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -244,21 +333,40 @@ def main():
 
     # the timed iterations did the work: every nonzero's phi sums to max(y, 1), so
     # the shape rows of this rank's users must hold exactly that mass (+ priors)
-    self_check = None
-    if n_loc * K <= 200_000_000:
-        ts = D.get_state("THETA_SHAPE")
-        got = float((ts - 0.3).sum())
-        if cfg["bias"]:
-            got += float((D.get_state("UBIAS_SHAPE") - 0.3).sum())
-        want_k = float(nnz_loc) if val is None else float(np.maximum(val, 1).astype(np.float64).sum())
-        del ts
-        if cfg["bias"]:
-            # the item-bias slot's share went to the items: bound instead of equality
-            self_check = {"user_side_mass_fraction": got / want_k, "ok": bool(0.0 < got <= want_k * (1 + 1e-9))}
-        else:
-            self_check = {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
-    tm = D.mean_timing(min(args.steps, 64))
+    ts = D.get_state_device("THETA_SHAPE", dev)
+    got = float((ts - 0.3).sum())
+    del ts
+    if cfg["bias"]:
+        got += float((D.get_state_device("UBIAS_SHAPE", dev) - 0.3).sum())
+    want_k = float(nnz_loc) if val is None else float(torch.clamp(val, min=1).to(torch.float64).sum())
+    if cfg["bias"]:
+        # the item-bias slot's share went to the items: bound instead of equality
+        self_check = {"user_side_mass_fraction": got / want_k, "ok": bool(0.0 < got <= want_k * (1 + 1e-9))}
+    else:
+        self_check = {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
     ab = D.algorithmic_bytes()
+    wi = D.work_info()
+
+    handover = {"generate_s": round(t_gen, 3), "upload_csr_device_s": round(t_upload, 3),
+                "set_state_device_s": round(t_state, 3)}
+    if args.host_handover and rank == 0:
+        # PCIe-inclusive set-up for a caller that holds host buffers (never part of `value`)
+        rp_h, col_h = rowptr.cpu().numpy(), col.cpu().numpy().view(np.uint32)
+        val_h = None if val is None else val.cpu().numpy()
+        D2 = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank)
+        t0 = time.perf_counter()
+        D2.upload_csr(rp_h, col_h, val_h)
+        handover["upload_csr_host_s"] = round(time.perf_counter() - t0, 3)
+        a = np.random.default_rng(1).random((n_loc, K))
+        t0 = time.perf_counter()
+        D2.set_state("THETA_E", a)
+        handover["set_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        t0 = time.perf_counter()
+        D2.get_state("THETA_E")
+        handover["get_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        D2.close()
+        del rp_h, col_h, val_h, a
+
     copy_gbs = None
     if rank == 0:
         # context for the roofline: what a plain device-to-device copy reaches on
@@ -280,49 +388,104 @@ def main():
         kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
         kms = tm[kern + "_ms"]
         kname, kbytes = f"phi_pass_kernel ({kern} pass)", ab[kern]
-        if kms == 0:
+        graph = kms == 0
+        if graph:
             # launch-bound workload: hpf_iterate replayed the iteration as one
             # hipGraph, so only the whole iteration is timed
             kms = tm["iteration_ms"]
             kname, kbytes = "whole iteration (hipGraph replay)", ab["phi_user"] + ab["phi_item"] + ab["rows"]
         achieved = kbytes / (kms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists() and not custom:
-            try:
-                traffic = json.loads(tf.read_text()).get(f"{args.config}:{kern}")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = (None, "custom workload") if custom or world > 1 else measured_traffic(cname, kern)
+        # bytes the sweeps really move: read the raw sums, write W (16 B per element);
+        # SURVEY.md's formula credits 32 (it assumes shape, rate, E and Elog all materialised)
+        Kp = K + (1 if cfg["bias"] else 0)
+        rows_moved = (n_loc + m) * Kp * 16
+
+        def gbs(b, ms):
+            return round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+
+        per_kernel = None if graph else {
+            "phi_item": {"algorithmic_bytes": ab["phi_item"], "ms": round(tm["phi_item_ms"], 4),
+                         "GBps": gbs(ab["phi_item"], tm["phi_item_ms"]),
+                         "note": "gathers rows of the user matrix: HBM-bound"},
+            "phi_user": {"algorithmic_bytes": ab["phi_user"], "ms": round(tm["phi_user_ms"], 4),
+                         "GBps": gbs(ab["phi_user"], tm["phi_user_ms"]),
+                         "note": "CACHE-INCLUSIVE: its gathers of item rows are largely served by L2 / Infinity "
+                                 "Cache, so this figure may exceed the HBM peak; it is not an HBM rate"},
+            "sweeps": {"bytes_moved": rows_moved, "survey_formula_bytes": ab["rows"],
+                       "ms": round(tm["sweep_user_ms"] + tm["sweep_item_ms"], 4),
+                       "GBps_moved": gbs(rows_moved, tm["sweep_user_ms"] + tm["sweep_item_ms"]),
+                       "note": "fp64-VALU-bound (digamma + exp per element), not HBM-bound"},
+        }
+        flags = " ".join(f for f, on in (("-hier", cfg["hier"]), ("-bias", cfg["bias"]),
+                                         ("-binary-data", cfg["binary"])) if on)
+        if strong:
+            workload = (f"{cname}: synthetic power-law ratings, {n_total} users x {m} items, {nnz_total} nonzeros "
+                        f"in total, K={K}, {flags}; users sharded over {world} GPUs by nonzeros (strong scaling)")
+        else:
+            workload = (f"{cname}: synthetic power-law ratings, {n_loc} users x {m} items and {nnz_loc} nonzeros "
+                        f"per GPU, K={K}, {flags}")
         out = {
             "metric": "rating-nonzeros/sec per CAVI iter (K=%d)" % K,
             "value": nnz_total * args.steps / dt,
             "unit": "rating-nonzeros/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else "f64", "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: synthetic power-law ratings, {n_loc} users x {m} items "
-                            f"and {nnz_loc} nonzeros per GPU, K={K}, "
-                            + " ".join(f for f, on in (("-hier", cfg["hier"]), ("-bias", cfg["bias"]),
-                                                       ("-binary-data", cfg["binary"])) if on),
-                "users_per_gpu": n_loc, "items": m, "nnz_per_gpu": nnz_loc, "nnz_total": nnz_total,
-                "K": K, "sharding": "users (contiguous ranges); items replicated; 1 all-reduce/iter"
-                if world > 1 else "single GPU",
+                "workload": workload,
+                "users_total": n_total, "users_per_gpu": n_loc, "items": m, "nnz_per_gpu": nnz_loc,
+                "nnz_total": nnz_total, "K": K,
+                "sharding": ("users (contiguous ranges balanced by nonzeros); items replicated; the item shape sums "
+                             f"({m * ld_x * 8 / 1e6:.0f} MB) all-reduced once per iteration underneath the user half")
+                if use_dist else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
+                "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
                 "hbm_copy_measured_GBps": copy_gbs,
+                "per_kernel": per_kernel,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+            "work": {k: wi[k] for k in ("user_segments", "item_segments", "user_long_rows", "item_long_rows",
+                                        "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R")},
+            "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
-            "iteration_algorithmic_GBps": (ab["phi_user"] + ab["phi_item"] + ab["rows"]) / (dt / args.steps) / 1e9,
+            # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user
+            # pass's share is served by caches, so this can sit above what HBM delivers.
+            "iteration_cache_inclusive_algorithmic_GBps":
+                (ab["phi_user"] + ab["phi_item"] + ab["rows"]) / (dt / args.steps) / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, rowptr, col, val)
+        if per_rank is not None:
+            comp = [r["phi_item_ms"] + r["combine_item_ms"] + r["phi_user_ms"] + r["combine_user_ms"]
+                    + r["sweep_user_ms"] + r["sweep_item_ms"] for r in per_rank]
+            out["per_rank"] = per_rank
+            out["exposed_allreduce_ms"] = {"max": max(r["exchange_wait_ms"] for r in per_rank),
+                                           "mean": sum(r["exchange_wait_ms"] for r in per_rank) / world}
+            out["compute_ms"] = {"max": max(comp), "min": min(comp)}
+            ref = ROOT / "profiles" / "c3_1gpu_reference.json"
+            if strong and not custom and cname == "C3" and ref.exists():
+                try:
+                    r1 = json.loads(ref.read_text())
+                    out["speedup_vs_1gpu_same_workload"] = {
+                        "value": r1["ms_per_step"] / out["ms_per_step"], "one_gpu_ms_per_step": r1["ms_per_step"],
+                        "source": "profiles/c3_1gpu_reference.json (whole C3 on one MI355X: "
+                                  "python bench.py --config C3 --steps 5 --warmup 2)"}
+                except Exception:
+                    pass
+        if world == 1 and not args.no_cpu_baseline and not force_dist:
+            s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
+            s_users = min(s_users, n_loc)
+            nz = int(rowptr[s_users])
+            out["cpu_baseline"] = cpu_baseline(cfg, rowptr[: s_users + 1].cpu().numpy(),
+                                               col[:nz].cpu().numpy().view(np.uint32),
+                                               None if val is None else val[:nz].cpu().numpy())
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     D.close()
     if use_dist:

@@ -37,6 +37,7 @@ EXPORTS = [
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
     "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_items_begin", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
     "hpf_algorithmic_bytes",
+    "hpf_get_work_info", "hpf_upload_csr_device", "hpf_get_csc", "hpf_set_state_device", "hpf_get_state_device",
 ]
 
 
@@ -56,6 +57,18 @@ class HpfTiming(C.Structure):
         ("phi_item_ms", C.c_float), ("combine_item_ms", C.c_float),
         ("sweep_user_ms", C.c_float), ("sweep_item_ms", C.c_float),
         ("iteration_ms", C.c_float), ("iterations", C.c_uint32),
+        ("exchange_wait_ms", C.c_float),
+    ]
+
+
+class HpfWorkInfo(C.Structure):
+    _fields_ = [
+        ("nnz", C.c_uint64),
+        ("user_segments", C.c_uint32), ("user_long_rows", C.c_uint32), ("user_huge_rows", C.c_uint32),
+        ("item_segments", C.c_uint32), ("item_long_rows", C.c_uint32), ("item_huge_rows", C.c_uint32),
+        ("phi_G", C.c_uint32), ("phi_R", C.c_uint32), ("phi_V", C.c_uint32),
+        ("sweep_G", C.c_uint32), ("sweep_R", C.c_uint32), ("ld", C.c_uint32),
+        ("graph_replay", C.c_uint32), ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -87,6 +100,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_destroy.argtypes = [vp]
     lib.hpf_destroy.restype = None
     lib.hpf_upload_csr.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
+    lib.hpf_get_work_info.argtypes = [vp, C.POINTER(HpfWorkInfo)]
+    lib.hpf_upload_csr_device.argtypes = [vp, vp, vp, vp]
+    lib.hpf_get_csc.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
+    lib.hpf_set_state_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.hpf_get_state_device.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.hpf_set_state.argtypes = [vp, C.c_int, dp, C.c_size_t]
     lib.hpf_get_state.argtypes = [vp, C.c_int, dp, C.c_size_t]
     lib.hpf_iterate.argtypes = [vp, C.c_int]
@@ -184,6 +202,48 @@ class Hpf:
             vp = _ptr(val, C.c_uint8)
         self._check(self.lib.hpf_upload_csr(self._h, _ptr(rowptr, C.c_int64),
                                             _ptr(col, C.c_uint32), vp))
+
+    def upload_csr_device(self, rowptr, col, val=None):
+        """CSR already resident in HBM: torch tensors on this handle's device
+        (int64 rowptr[n+1], int32/uint32-as-int32 col[nnz], uint8 val[nnz] or None).
+        Torch is plumbing here: only data_ptr() crosses the C-ABI."""
+        import torch
+        if rowptr.dtype != torch.int64 or rowptr.numel() != self.n_users + 1 or not rowptr.is_cuda:
+            raise ValueError("rowptr: int64 device tensor with n_users + 1 entries")
+        if col.dtype not in (torch.int32, torch.uint32) or not col.is_cuda:
+            raise ValueError("col: 32-bit device tensor")
+        if val is not None and (val.dtype != torch.uint8 or not val.is_cuda or val.numel() != col.numel()):
+            raise ValueError("val: uint8 device tensor as long as col")
+        rowptr, col = rowptr.contiguous(), col.contiguous()
+        val = None if val is None else val.contiguous()
+        torch.cuda.synchronize(rowptr.device)             # the producer's work is complete
+        self._check(self.lib.hpf_upload_csr_device(
+            self._h, C.c_void_p(rowptr.data_ptr()), C.c_void_p(col.data_ptr() if col.numel() else None),
+            C.c_void_p(val.data_ptr()) if val is not None and val.numel() else None))
+
+    def get_csc(self, nnz: int, with_vals=True):
+        """host copies of the item-major view: colptr[m+1], users[nnz], vals[nnz] | None"""
+        colptr = np.empty(self.n_items + 1, np.int64)
+        users = np.empty(nnz, np.uint32)
+        vals = np.empty(nnz, np.uint8) if with_vals else None
+        self._check(self.lib.hpf_get_csc(self._h, _ptr(colptr, C.c_int64), _ptr(users, C.c_uint32),
+                                         _ptr(vals, C.c_uint8) if with_vals else None))
+        return colptr, users, vals
+
+    def set_state_device(self, which: str, t):
+        """like set_state for a float64 torch tensor on this handle's device"""
+        import torch
+        if t.dtype != torch.float64 or not t.is_cuda or tuple(t.shape) != self.state_shape(which):
+            raise ValueError(f"{which}: float64 device tensor of shape {self.state_shape(which)}")
+        t = t.contiguous()
+        torch.cuda.synchronize(t.device)
+        self._check(self.lib.hpf_set_state_device(self._h, STATE[which], C.c_void_p(t.data_ptr()), t.numel()))
+
+    def get_state_device(self, which: str, device=None):
+        import torch
+        out = torch.empty(self.state_shape(which), dtype=torch.float64, device=device or "cuda")
+        self._check(self.lib.hpf_get_state_device(self._h, STATE[which], C.c_void_p(out.data_ptr()), out.numel()))
+        return out
 
     def state_shape(self, which: str):
         obj = STATE[which] // 4
@@ -332,6 +392,11 @@ class Hpf:
         t = HpfTiming()
         self._check(self.lib.hpf_mean_timing(self._h, int(n_last), C.byref(t)))
         return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
+
+    def work_info(self) -> dict:
+        w = HpfWorkInfo()
+        self._check(self.lib.hpf_get_work_info(self._h, C.byref(w)))
+        return {f: getattr(w, f) for f, _ in HpfWorkInfo._fields_ if f != "reserved"}
 
     def algorithmic_bytes(self) -> dict:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -1,0 +1,252 @@
+// hpf_build.hpp -- gfx950 kernels of the device-side hand-over (hpf_upload_csr /
+// hpf_upload_csr_device): the item-major (CSC) view of the ratings is built in
+// HBM from the user-major CSR by a hand-written stable LSD radix sort on the
+// item id, so that inside an item the users stay ascending -- the order in
+// which the reference's serial loop (hgaprec.cc:1340-1345) reaches them, and
+// bit for bit the order of a serial counting sort.
+//
+//   item_hist_kernel      per-item degree (integer atomics: order-free) + range check
+//   scan_*_kernel         exclusive scan (3 phases, fixed shape -> same result every run)
+//   radix_count_kernel    per wave-tile digit histogram
+//   radix_scatter_kernel  stable scatter of (key, user, rating): ranks by wave ballots,
+//                         per-wave running digit counters in LDS, no atomics on order
+//   repack_*_kernel       dense [rows x cols] <-> padded [rows x ld] column block
+//
+// All integer / byte work, HBM-bound; nothing here is shaped for MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpf {
+
+// ---------------------------------------------------------------------
+// per-item degree: cnt[col[j]]++ ; bad[0] |= 1 when an index is out of range
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void item_hist_kernel(const uint32_t *col, uint64_t nnz, uint32_t m,
+                                                        uint32_t *cnt, uint32_t *bad)
+{
+  bool b = false;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz;
+       j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = col[j];
+    if (c < m) atomicAdd(&cnt[c], 1u); else b = true;
+  }
+  if (b) atomicOr(bad, 1u);
+}
+
+// ---------------------------------------------------------------------
+// exclusive scan of n values (IN = uint32_t or uint64_t) into uint64_t.
+// Chunk = SCAN_CHUNK consecutive elements per 256-thread block.
+//   1. scan_reduce_kernel : block sums
+//   2. scan_spine_kernel  : one block turns the block sums into exclusive prefixes
+//   3. scan_apply_kernel  : block-local exclusive scan + its prefix; out[n] = total
+// in == out is allowed for IN = uint64_t (in place).
+// ---------------------------------------------------------------------
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_CHUNK = 256 * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// inclusive scan over the 256 threads of a block; *total = block sum
+__device__ __forceinline__ uint64_t block_incl_scan_u64(uint64_t v, uint64_t *total)
+{
+  __shared__ uint64_t wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  v = wave_incl_scan_u64(v, lane);
+  __syncthreads();                       // wsum may still be read by a previous call
+  if (lane == 63) wsum[wv] = v;
+  __syncthreads();
+  uint64_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { if (w < wv) off += wsum[w]; tot += wsum[w]; }
+  *total = tot;
+  return v + off;
+}
+
+template <typename IN>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const IN *in, uint64_t n, uint64_t *bsum)
+{
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) if (base + k < n) s += (uint64_t)in[base + k];
+  uint64_t tot;
+  (void)block_incl_scan_u64(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void scan_spine_kernel(uint64_t *bsum, uint64_t nb)
+{
+  uint64_t carry = 0;
+  for (uint64_t b0 = 0; b0 < nb; b0 += 256) {
+    const uint64_t i = b0 + threadIdx.x;
+    const uint64_t v = i < nb ? bsum[i] : 0;
+    uint64_t tot;
+    const uint64_t inc = block_incl_scan_u64(v, &tot);
+    if (i < nb) bsum[i] = carry + inc - v;
+    carry += tot;
+  }
+}
+
+template <typename IN>
+__global__ __launch_bounds__(256) void scan_apply_kernel(const IN *in, uint64_t n, const uint64_t *bsum,
+                                                         uint64_t *out, int write_total)
+{
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+  uint64_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? (uint64_t)in[base + k] : 0; s += v[k]; }
+  uint64_t tot;
+  const uint64_t inc = block_incl_scan_u64(s, &tot);
+  uint64_t run = bsum[blockIdx.x] + inc - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  // the element that closes the last chunk carries the grand total
+  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = bsum[blockIdx.x] + tot;
+}
+
+// ---------------------------------------------------------------------
+// stable LSD radix sort pass on 8-bit digits of the item id.
+// A wave owns RADIX_ROUNDS * 64 consecutive elements (a tile); the element
+// order inside a digit is (tile, round, lane) = the input order.
+//   counts / offsets layout: [digit][tile]  (scan over it gives the global
+//   position of the first element of that digit in that tile)
+// ---------------------------------------------------------------------
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_DIGITS = 1 << RADIX_BITS;
+constexpr int RADIX_ROUNDS = 64;
+constexpr int RADIX_TILE = RADIX_ROUNDS * 64;
+
+__global__ __launch_bounds__(256) void radix_count_kernel(const uint32_t *keys, uint64_t nnz, uint32_t shift,
+                                                          uint64_t ntiles, uint64_t *counts)
+{
+  __shared__ uint32_t hist[4][RADIX_DIGITS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t tile = (uint64_t)blockIdx.x * 4 + wv;
+  for (int d = lane; d < RADIX_DIGITS; d += 64) hist[wv][d] = 0;
+  __syncthreads();
+  if (tile < ntiles) {
+    const uint64_t base = tile * RADIX_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RADIX_ROUNDS; ++r) {
+      const uint64_t j = base + (uint64_t)r * 64 + lane;
+      if (j < nnz) atomicAdd(&hist[wv][(keys[j] >> shift) & (RADIX_DIGITS - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  if (tile < ntiles)
+    for (int d = lane; d < RADIX_DIGITS; d += 64) counts[(uint64_t)d * ntiles + tile] = hist[wv][d];
+}
+
+// rowptr: user CSR row pointers (first pass: the user of nonzero j is found by
+// bisection inside the tile's row window); users_in: payload of later passes.
+struct RadixArgs {
+  const uint32_t *keys_in;    // item ids in input order
+  const uint32_t *users_in;   // NULL on the first pass
+  const uint8_t  *vals_in;    // NULL with -binary-data
+  const int64_t  *rowptr;     // [n+1], first pass only
+  uint32_t        n_rows;
+  uint32_t       *keys_out;   // NULL on the last pass
+  uint32_t       *users_out;
+  uint8_t        *vals_out;
+  const uint64_t *offsets;    // [digit][tile] exclusive scan of the counts
+  uint64_t        nnz, ntiles;
+  uint32_t        shift;
+};
+
+// last row r with rowptr[r] <= j, r in [lo, hi]
+__device__ __forceinline__ uint32_t row_of(const int64_t *rowptr, uint32_t lo, uint32_t hi, int64_t j)
+{
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo + 1) / 2;
+    if (rowptr[mid] <= j) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(RadixArgs a)
+{
+  __shared__ uint64_t pos[4][RADIX_DIGITS];      // next output position of each digit, per wave
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t tile = (uint64_t)blockIdx.x * 4 + wv;
+  if (tile >= a.ntiles) return;                  // whole wave leaves: no block-wide barrier below
+  for (int d = lane; d < RADIX_DIGITS; d += 64) pos[wv][d] = a.offsets[(uint64_t)d * a.ntiles + tile];
+  const uint64_t base = tile * RADIX_TILE;
+  const uint64_t end = (base + RADIX_TILE < a.nnz) ? base + RADIX_TILE : a.nnz;
+  uint32_t row_lo = 0, row_hi = 0;
+  if (!a.users_in) {
+    row_lo = row_of(a.rowptr, 0, a.n_rows - 1, (int64_t)base);
+    row_hi = row_of(a.rowptr, row_lo, a.n_rows - 1, (int64_t)(end - 1));
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (int r = 0; r < RADIX_ROUNDS; ++r) {
+    const uint64_t j = base + (uint64_t)r * 64 + lane;
+    const bool ok = j < end;
+    uint32_t key = 0, user = 0, val = 0;
+    if (ok) {
+      key = a.keys_in[j];
+      user = a.users_in ? a.users_in[j] : row_of(a.rowptr, row_lo, row_hi, (int64_t)j);
+      if (a.vals_in) val = a.vals_in[j];
+    }
+    const uint32_t d = (key >> a.shift) & (RADIX_DIGITS - 1);
+    // lanes holding the same digit (inactive lanes match nobody)
+    uint64_t same = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+      const uint64_t bal = __ballot((d >> b) & 1u);
+      same &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = (uint32_t)__popcll(same & lt), cnt = (uint32_t)__popcll(same);
+    uint64_t p = 0;
+    if (ok) p = pos[wv][d];
+    // every lane has read its digit's position before the leaders advance it
+    // (LDS operations of one wave complete in issue order)
+    __builtin_amdgcn_wave_barrier();
+    if (ok && before == 0) pos[wv][d] = p + cnt;
+    __builtin_amdgcn_wave_barrier();
+    if (ok) {
+      p += before;
+      if (a.keys_out) a.keys_out[p] = key;
+      a.users_out[p] = user;
+      if (a.vals_out) a.vals_out[p] = (uint8_t)val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// dense [rows x cols] block  <->  columns [col0, col0 + cols) of a padded
+// [rows x ld] matrix, rows [r0, r0 + rows).  dense is contiguous.
+// ---------------------------------------------------------------------
+__global__ void repack_in_kernel(const double *dense, double *padded, uint64_t rows, uint32_t cols,
+                                 uint32_t ld, uint32_t col0)
+{
+  const uint64_t n = rows * cols;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = e / cols; const uint32_t c = (uint32_t)(e % cols);
+    padded[r * ld + col0 + c] = dense[e];
+  }
+}
+__global__ void repack_out_kernel(const double *padded, double *dense, uint64_t rows, uint32_t cols,
+                                  uint32_t ld, uint32_t col0)
+{
+  const uint64_t n = rows * cols;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = e / cols; const uint32_t c = (uint32_t)(e % cols);
+    dense[e] = padded[r * ld + col0 + c];
+  }
+}
+
+}  // namespace hpf

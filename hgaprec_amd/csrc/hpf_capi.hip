@@ -11,6 +11,7 @@
 //   exchange   [m x ld | ld]: item S rows followed by sum_u E[theta_u,:]
 #include "../../include/hpf.h"
 #include "hpf_kernels.hpp"
+#include "hpf_build.hpp"
 
 #include <dlfcn.h>
 
@@ -77,8 +78,17 @@ struct hpf_handle {
   Side u, it;
   double *exch = nullptr; size_t exch_count = 0; bool exch_external = false;
   double *logfact = nullptr;
-  int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ELBO kernel)
+  int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ranking mask, CSC build)
+  int64_t *colptr_dev = nullptr;   // item-major (CSC) column pointers, built on device
   uint64_t nnz = 0;
+  // pinned double buffer for host <-> device hand-over (hpf_upload_csr, hpf_set_state,
+  // hpf_get_state): pageable hipMemcpy runs at ~4 GB/s, the staged pipeline at the
+  // host memcpy rate.  HPF_H2D=plain|staged|register picks the carrier.
+  void *stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  int xfer_mode = 1;               // 0 plain, 1 staged, 2 hipHostRegister
+  unsigned xfer_threads = 4;
   bool have_csr = false, derived_dirty = true;
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
@@ -90,7 +100,7 @@ struct hpf_handle {
                                         // short hot/cold segments cost more than the L2 hits save; kept as a knob.
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
-  hipEvent_t evr[RING][7] = {};
+  hipEvent_t evr[RING][8] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
   uint32_t ev_count = 0;                        // iterations recorded so far
   void *comm = nullptr;                 // ncclComm_t once hpf_comm_init succeeded
@@ -121,6 +131,7 @@ struct RcclApi {
   int (*CommInitRank)(void **, int, IdByValue /* ncclUniqueId by value */, int) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, void *) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommGetAsyncError)(void *, int *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -138,6 +149,7 @@ const char *load_rccl()
   a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, void *))dlsym(lib, "ncclAllReduce");
   a.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
   a.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+  a.CommGetAsyncError = (int (*)(void *, int *))dlsym(lib, "ncclCommGetAsyncError");   // optional
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
     return "librccl.so lacks an expected symbol";
   g_rccl = a;
@@ -146,6 +158,10 @@ const char *load_rccl()
 }  // namespace
 
 namespace {
+
+// an asynchronous RCCL failure (a peer died, a link error) surfaces here, once
+// per iteration, instead of as a hang in a later collective
+int check_comm_async(hpf_handle *h);
 
 #define HIPCHK(h, expr)                                                        \
   do {                                                                         \
@@ -296,6 +312,200 @@ int check_launch(hpf_handle *h, const char *what)
   return HPF_OK;
 }
 
+int check_comm_async(hpf_handle *h)
+{
+  if (!h->comm || !g_rccl.CommGetAsyncError) return HPF_OK;
+  int st = 0;
+  const int rc = g_rccl.CommGetAsyncError(h->comm, &st);
+  if (rc != 0 || (st != 0 && st != 7 /* ncclInProgress */)) {
+    h->err = std::string("RCCL asynchronous error: ") + g_rccl.GetErrorString(rc != 0 ? rc : st);
+    return HPF_ERR_HIP;
+  }
+  return HPF_OK;
+}
+
+// ---- host <-> device hand-over ----------------------------------------------
+// Pageable hipMemcpy is staged by the runtime at ~4 GB/s; here the bytes go
+// through two pinned buffers filled / drained by a few host threads while the
+// other buffer is on the wire (HPF_H2D=staged, default), or the caller's pages
+// are pinned for the duration of the copy (HPF_H2D=register), or it is left to
+// the runtime (HPF_H2D=plain).
+constexpr size_t STAGE_BYTES = 64u << 20;
+
+int ensure_stage(hpf_handle *h)
+{
+  if (h->stage[0]) return HPF_OK;
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(h, hipHostMalloc(&h->stage[k], STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+  }
+  h->stage_bytes = STAGE_BYTES;
+  return HPF_OK;
+}
+
+void par_memcpy(void *dst, const void *src, size_t bytes, unsigned T)
+{
+  if (T <= 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
+  const size_t per = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t) {
+    const size_t o = (size_t)t * per;
+    if (o >= bytes) break;
+    const size_t len = std::min(per, bytes - o);
+    th.emplace_back([=] { memcpy((char *)dst + o, (const char *)src + o, len); });
+  }
+  for (auto &x : th) x.join();
+}
+
+// contiguous host -> device; returns after the bytes have left `src`
+int h2d(hpf_handle *h, void *dst, const void *src, size_t bytes)
+{
+  if (!bytes) return HPF_OK;
+  if (h->xfer_mode == 2 && bytes >= (1u << 20)) {
+    if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+      hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      (void)hipHostUnregister(const_cast<void *>(src));
+      if (e != hipSuccess) { h->err = std::string("h2d: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+      return HPF_OK;
+    }
+    (void)hipGetLastError();             // not registrable (e.g. read-only mapping): stage it
+  }
+  if (h->xfer_mode == 0 || bytes < (1u << 20)) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
+  int rc;
+  if ((rc = ensure_stage(h))) return rc;
+  size_t off = 0; int k = 0;
+  bool used[2] = {false, false};
+  while (off < bytes) {
+    const size_t len = std::min(h->stage_bytes, bytes - off);
+    if (used[k]) HIPCHK(h, hipEventSynchronize(h->stage_ev[k]));
+    par_memcpy(h->stage[k], (const char *)src + off, len, h->xfer_threads);
+    HIPCHK(h, hipMemcpyAsync((char *)dst + off, h->stage[k], len, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->stage_ev[k], h->stream));
+    used[k] = true; k ^= 1; off += len;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
+// contiguous device -> host (synchronous)
+int d2h(hpf_handle *h, void *dst, const void *src, size_t bytes)
+{
+  if (!bytes) return HPF_OK;
+  if (h->xfer_mode == 2 && bytes >= (1u << 20)) {
+    if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) {
+      hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      (void)hipHostUnregister(dst);
+      if (e != hipSuccess) { h->err = std::string("d2h: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+      return HPF_OK;
+    }
+    (void)hipGetLastError();
+  }
+  if (h->xfer_mode == 0 || bytes < (1u << 20)) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
+  int rc;
+  if ((rc = ensure_stage(h))) return rc;
+  // chunk c is copied out of its pinned buffer while chunk c+1 is on the wire
+  size_t off = 0, prev_off = 0, prev_len = 0; int k = 0;
+  bool have_prev = false;
+  while (off < bytes || have_prev) {
+    size_t len = 0;
+    if (off < bytes) {
+      len = std::min(h->stage_bytes, bytes - off);
+      HIPCHK(h, hipMemcpyAsync(h->stage[k], (const char *)src + off, len, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipEventRecord(h->stage_ev[k], h->stream));
+    }
+    if (have_prev) {
+      HIPCHK(h, hipEventSynchronize(h->stage_ev[k ^ 1]));
+      par_memcpy((char *)dst + prev_off, h->stage[k ^ 1], prev_len, h->xfer_threads);
+    }
+    have_prev = len > 0; prev_off = off; prev_len = len; off += len; k ^= 1;
+  }
+  return HPF_OK;
+}
+
+uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 16384); }
+
+// dense [rows x cols] host <-> columns [col0, col0+cols) of the padded device
+// matrix.  Full-width blocks (cols == ld) move straight; anything else goes
+// through a contiguous device chunk and a repack kernel.
+int copy_in(hpf_handle *h, double *dev, uint32_t ld, uint32_t col0, const double *host,
+            uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == ld && col0 == 0) return h2d(h, dev, host, (size_t)rows * cols * 8);
+  const uint64_t rows_per = std::max<uint64_t>(1, (256u << 20) / ((uint64_t)cols * 8));
+  double *tmp = nullptr; int rc;
+  if ((rc = dalloc(h, &tmp, (size_t)std::min<uint64_t>(rows, rows_per) * cols))) return rc;
+  for (uint64_t r0 = 0; r0 < rows && !rc; r0 += rows_per) {
+    const uint64_t nr = std::min<uint64_t>(rows_per, rows - r0);
+    if ((rc = h2d(h, tmp, host + r0 * cols, (size_t)nr * cols * 8))) break;
+    hipLaunchKernelGGL(repack_in_kernel, dim3(grid_for(nr * cols)), dim3(256), 0, h->stream, tmp,
+                       dev + r0 * ld, nr, cols, ld, col0);
+    rc = check_launch(h, "repack_in_kernel");
+  }
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "copy_in: stream error"; rc = HPF_ERR_HIP; }
+  dfree(tmp);
+  return rc;
+}
+int copy_out(hpf_handle *h, const double *dev, uint32_t ld, uint32_t col0, double *host,
+             uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == ld && col0 == 0) return d2h(h, host, dev, (size_t)rows * cols * 8);
+  const uint64_t rows_per = std::max<uint64_t>(1, (256u << 20) / ((uint64_t)cols * 8));
+  double *tmp = nullptr; int rc;
+  if ((rc = dalloc(h, &tmp, (size_t)std::min<uint64_t>(rows, rows_per) * cols))) return rc;
+  for (uint64_t r0 = 0; r0 < rows && !rc; r0 += rows_per) {
+    const uint64_t nr = std::min<uint64_t>(rows_per, rows - r0);
+    hipLaunchKernelGGL(repack_out_kernel, dim3(grid_for(nr * cols)), dim3(256), 0, h->stream,
+                       dev + r0 * ld, tmp, nr, cols, ld, col0);
+    if ((rc = check_launch(h, "repack_out_kernel"))) break;
+    rc = d2h(h, host + r0 * cols, tmp, (size_t)nr * cols * 8);
+  }
+  dfree(tmp);
+  return rc;
+}
+// the same for a caller's DEVICE buffer (hpf_set_state_device / hpf_get_state_device)
+int copy_in_dev(hpf_handle *h, double *dev, uint32_t ld, uint32_t col0, const double *src,
+                uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == ld && col0 == 0)
+    HIPCHK(h, hipMemcpyAsync(dev, src, (size_t)rows * cols * 8, hipMemcpyDeviceToDevice, h->stream));
+  else {
+    hipLaunchKernelGGL(repack_in_kernel, dim3(grid_for((uint64_t)rows * cols)), dim3(256), 0, h->stream, src,
+                       dev, (uint64_t)rows, cols, ld, col0);
+    int rc = check_launch(h, "repack_in_kernel");
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+int copy_out_dev(hpf_handle *h, const double *dev, uint32_t ld, uint32_t col0, double *dst,
+                 uint32_t rows, uint32_t cols)
+{
+  if (!rows || !cols) return HPF_OK;
+  if (cols == ld && col0 == 0)
+    HIPCHK(h, hipMemcpyAsync(dst, dev, (size_t)rows * cols * 8, hipMemcpyDeviceToDevice, h->stream));
+  else {
+    hipLaunchKernelGGL(repack_out_kernel, dim3(grid_for((uint64_t)rows * cols)), dim3(256), 0, h->stream, dev,
+                       dst, (uint64_t)rows, cols, ld, col0);
+    int rc = check_launch(h, "repack_out_kernel");
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
+}
+
 // ---- work lists -----------------------------------------------------------
 // segments of at most seg_max nonzeros for the row parts [start[r], start[r]+len[r]);
 // skip_empty: rows with len 0 get no segment (cold phase), else one empty segment
@@ -327,9 +537,11 @@ void build_segments(const std::vector<int64_t> &start, const std::vector<uint32_
   *slot_io = slot;
 }
 
-// deg_oth: degrees of the OTHER side's rows (rows_oth of them), used to pick the hot set
-int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
-                     const uint32_t *idx, const uint8_t *val, uint64_t nnz,
+// Work lists of one side.  s.idx / s.val already hold the side's nonzeros in HBM
+// (row-major for `ptr`); ptr / ptr_oth are HOST copies of this side's and the
+// other side's row pointers.  Only the experimental hot/cold split (HPF_HOT_BYTES)
+// touches the nonzeros again: it reorders them inside each row on the host.
+int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows, uint64_t nnz,
                      const int64_t *ptr_oth, uint32_t rows_oth)
 {
   for (int p = 0; p < 2; ++p) {
@@ -337,9 +549,10 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
     s.segs[p] = nullptr; s.longrows[p] = s.grouprows[p] = s.hugerows[p] = nullptr;
     s.nseg[p] = s.nlong[p] = s.ngroup[p] = s.nhuge[p] = 0;
   }
-  dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
-  s.partial = nullptr; s.partial2 = nullptr; s.idx = nullptr; s.val = nullptr;
+  dfree(s.partial); dfree(s.partial2);
+  s.partial = nullptr; s.partial2 = nullptr;
   s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0;
+  int rc;
 
   // ---- hot set: the highest-degree other-side rows whose W rows fit in one L2
   const uint64_t row_bytes = (uint64_t)h->ld * 8;
@@ -366,18 +579,19 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
   // ---- (re)order the nonzeros of each row: hot ones first, stable
   std::vector<int64_t> start0(rows), start1(rows);
   std::vector<uint32_t> len0(rows), len1(rows, 0);
-  std::vector<uint32_t> ridx; std::vector<uint8_t> rval;
-  const uint32_t *up_idx = idx; const uint8_t *up_val = val;
   if (s.phases == 2) {
-    ridx.resize(nnz); if (val) rval.resize(nnz);
+    std::vector<uint32_t> idx(nnz), ridx(nnz); std::vector<uint8_t> val, rval;
+    if ((rc = d2h(h, idx.data(), s.idx, nnz * 4))) return rc;
+    if (s.val) { val.resize(nnz); rval.resize(nnz); if ((rc = d2h(h, val.data(), s.val, nnz))) return rc; }
     for (uint32_t r = 0; r < rows; ++r) {
       const int64_t a = ptr[r], b = ptr[r + 1];
       int64_t w = a;
-      for (int64_t j = a; j < b; ++j) if (hot[idx[j]]) { ridx[w] = idx[j]; if (val) rval[w] = val[j]; ++w; }
+      for (int64_t j = a; j < b; ++j) if (hot[idx[j]]) { ridx[w] = idx[j]; if (s.val) rval[w] = val[j]; ++w; }
       start0[r] = a; len0[r] = (uint32_t)(w - a); start1[r] = w; len1[r] = (uint32_t)(b - w);
-      for (int64_t j = a; j < b; ++j) if (!hot[idx[j]]) { ridx[w] = idx[j]; if (val) rval[w] = val[j]; ++w; }
+      for (int64_t j = a; j < b; ++j) if (!hot[idx[j]]) { ridx[w] = idx[j]; if (s.val) rval[w] = val[j]; ++w; }
     }
-    up_idx = ridx.data(); up_val = val ? rval.data() : nullptr;
+    if ((rc = h2d(h, s.idx, ridx.data(), nnz * 4))) return rc;
+    if (s.val && (rc = h2d(h, s.val, rval.data(), nnz))) return rc;
   } else {
     for (uint32_t r = 0; r < rows; ++r) { start0[r] = ptr[r]; len0[r] = (uint32_t)(ptr[r + 1] - ptr[r]); }
   }
@@ -403,84 +617,103 @@ int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows,
     longs[p].swap(keep);
   }
   s.npartial2 = np2;
-  int rc;
   for (int p = 0; p < 2; ++p) {
     s.ngroup[p] = (uint32_t)groups[p].size(); s.nhuge[p] = (uint32_t)huge[p].size();
     if (s.ngroup[p]) {
       if ((rc = dalloc(h, &s.grouprows[p], groups[p].size()))) return rc;
       if ((rc = dalloc(h, &s.hugerows[p], huge[p].size()))) return rc;
-      HIPCHK(h, hipMemcpyAsync(s.grouprows[p], groups[p].data(), groups[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
-      HIPCHK(h, hipMemcpyAsync(s.hugerows[p], huge[p].data(), huge[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+      if ((rc = h2d(h, s.grouprows[p], groups[p].data(), groups[p].size() * sizeof(LongRow)))) return rc;
+      if ((rc = h2d(h, s.hugerows[p], huge[p].data(), huge[p].size() * sizeof(LongRow)))) return rc;
     }
     s.nseg[p] = (uint32_t)segs[p].size(); s.nlong[p] = (uint32_t)longs[p].size();
     if ((rc = dalloc(h, &s.segs[p], segs[p].size()))) return rc;
     if ((rc = dalloc(h, &s.longrows[p], longs[p].size()))) return rc;
-    if (!segs[p].empty())
-      HIPCHK(h, hipMemcpyAsync(s.segs[p], segs[p].data(), segs[p].size() * sizeof(Seg), hipMemcpyHostToDevice, h->stream));
-    if (!longs[p].empty())
-      HIPCHK(h, hipMemcpyAsync(s.longrows[p], longs[p].data(), longs[p].size() * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+    if ((rc = h2d(h, s.segs[p], segs[p].data(), segs[p].size() * sizeof(Seg)))) return rc;
+    if ((rc = h2d(h, s.longrows[p], longs[p].data(), longs[p].size() * sizeof(LongRow)))) return rc;
   }
   if ((rc = dalloc(h, &s.partial, (size_t)np * h->ld))) return rc;
   if (np2 && (rc = dalloc(h, &s.partial2, (size_t)np2 * h->ld))) return rc;
-  if ((rc = dalloc(h, &s.idx, (size_t)nnz))) return rc;
-  if (nnz)
-    HIPCHK(h, hipMemcpyAsync(s.idx, up_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  if (val) {
-    if ((rc = dalloc(h, &s.val, (size_t)nnz))) return rc;
-    if (nnz)
-      HIPCHK(h, hipMemcpyAsync(s.val, up_val, nnz, hipMemcpyHostToDevice, h->stream));
-  }
-  HIPCHK(h, hipStreamSynchronize(h->stream));   // host vectors die here
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return HPF_OK;
 }
 
-// dense [rows x cols] host <-> padded device column block.  Wide blocks go
-// through a strided DMA; single columns (bias objects) are staged through a
-// contiguous device buffer and a scatter/gather kernel (a 2-D copy of 8-byte
-// rows is one descriptor per row).
-int copy_in(hpf_handle *h, double *dev, uint32_t ld, uint32_t col0, const double *host,
-            uint32_t rows, uint32_t cols)
+// exclusive scan of n counters (uint32 or uint64) into uint64 out[0..n) (+ out[n] = total)
+template <typename IN>
+int device_scan(hpf_handle *h, const IN *in, uint64_t n, uint64_t *out, bool write_total)
 {
-  if (!rows || !cols) return HPF_OK;
-  if (cols == 1) {
-    double *tmp = nullptr; int rc;
-    if ((rc = dalloc(h, &tmp, rows))) return rc;
-    hipError_t e = hipMemcpyAsync(tmp, host, (size_t)rows * 8, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(column_scatter_kernel, dim3(std::min<uint32_t>((rows + 255) / 256, 4096)),
-                         dim3(256), 0, h->stream, tmp, dev + col0, rows, ld);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    dfree(tmp);
-    if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
+  if (n == 0) {
+    if (write_total) HIPCHK(h, hipMemsetAsync(out, 0, 8, h->stream));
     return HPF_OK;
   }
-  HIPCHK(h, hipMemcpy2DAsync(dev + col0, (size_t)ld * 8, host, (size_t)cols * 8, (size_t)cols * 8,
-                             rows, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return HPF_OK;
+  const uint64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  uint64_t *bsum = nullptr; int rc;
+  if ((rc = dalloc(h, &bsum, (size_t)nb))) return rc;
+  hipLaunchKernelGGL((scan_reduce_kernel<IN>), dim3((uint32_t)nb), dim3(256), 0, h->stream, in, n, bsum);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(256), 0, h->stream, bsum, nb);
+  hipLaunchKernelGGL((scan_apply_kernel<IN>), dim3((uint32_t)nb), dim3(256), 0, h->stream, in, n, bsum, out,
+                     write_total ? 1 : 0);
+  rc = check_launch(h, "device_scan");
+  hipError_t e = hipStreamSynchronize(h->stream);
+  dfree(bsum);
+  if (!rc && e != hipSuccess) { h->err = std::string("device_scan: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; }
+  return rc;
 }
-int copy_out(hpf_handle *h, const double *dev, uint32_t ld, uint32_t col0, double *host,
-             uint32_t rows, uint32_t cols)
+
+// Item-major view of the ratings, built in HBM: h->u.idx / h->u.val (CSR order)
+// and h->rowptr_dev are in place; fills h->colptr_dev, h->it.idx, h->it.val.
+// Stable LSD radix sort on the item id => users ascending inside an item.
+int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
 {
-  if (!rows || !cols) return HPF_OK;
-  if (cols == 1) {
-    double *tmp = nullptr; int rc;
-    if ((rc = dalloc(h, &tmp, rows))) return rc;
-    hipLaunchKernelGGL(column_gather_kernel, dim3(std::min<uint32_t>((rows + 255) / 256, 4096)),
-                       dim3(256), 0, h->stream, dev + col0, tmp, rows, ld);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(host, tmp, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream);
+  int rc;
+  uint32_t *cnt = nullptr, *bad = nullptr;
+  uint32_t *kbuf[2] = {nullptr, nullptr}, *ut = nullptr; uint8_t *vt = nullptr; uint64_t *counts = nullptr;
+  dfree(h->colptr_dev); h->colptr_dev = nullptr;
+  dfree(h->it.idx); dfree(h->it.val); h->it.idx = nullptr; h->it.val = nullptr;
+  do {
+    if ((rc = dalloc(h, &h->colptr_dev, (size_t)m + 1))) break;
+    if ((rc = dalloc(h, &h->it.idx, (size_t)nnz))) break;
+    if (h->u.val && (rc = dalloc(h, &h->it.val, (size_t)nnz))) break;
+    if (nnz == 0) break;
+    if ((rc = dalloc(h, &cnt, m)) || (rc = dalloc(h, &bad, 1))) break;
+    hipLaunchKernelGGL(item_hist_kernel, dim3(grid_for(nnz)), dim3(256), 0, h->stream, h->u.idx, nnz, m, cnt, bad);
+    if ((rc = check_launch(h, "item_hist_kernel"))) break;
+    uint32_t hb = 0;
+    hipError_t e = hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    dfree(tmp);
-    if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
-    return HPF_OK;
-  }
-  HIPCHK(h, hipMemcpy2DAsync(host, (size_t)cols * 8, dev + col0, (size_t)ld * 8, (size_t)cols * 8,
-                             rows, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return HPF_OK;
+    if (e != hipSuccess) { h->err = std::string("item_hist_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    if (hb) { h->err = "item index out of range"; rc = HPF_ERR_INVALID; break; }
+    if ((rc = device_scan<uint32_t>(h, cnt, m, (uint64_t *)h->colptr_dev, true))) break;
+
+    uint32_t bits = 0;
+    while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)m) ++bits;
+    const uint32_t P = std::max<uint32_t>(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
+    const uint64_t ntiles = (nnz + RADIX_TILE - 1) / RADIX_TILE;
+    const uint32_t nblk = (uint32_t)((ntiles + 3) / 4);
+    if ((rc = dalloc(h, &counts, (size_t)ntiles * RADIX_DIGITS))) break;
+    if (P >= 2 && ((rc = dalloc(h, &kbuf[0], (size_t)nnz)) || (rc = dalloc(h, &ut, (size_t)nnz)))) break;
+    if (P >= 3 && (rc = dalloc(h, &kbuf[1], (size_t)nnz))) break;
+    if (P >= 2 && h->u.val && (rc = dalloc(h, &vt, (size_t)nnz))) break;
+    for (uint32_t p = 0; p < P && !rc; ++p) {
+      RadixArgs a;
+      a.keys_in = p == 0 ? h->u.idx : kbuf[(p - 1) & 1];
+      const bool out_final = ((P - 1 - p) & 1u) == 0;      // the last pass lands in it.idx / it.val
+      a.users_in = p == 0 ? nullptr : (out_final ? ut : h->it.idx);
+      a.vals_in = !h->u.val ? nullptr : p == 0 ? h->u.val : (out_final ? vt : h->it.val);
+      a.rowptr = h->rowptr_dev; a.n_rows = n;
+      a.keys_out = p + 1 == P ? nullptr : kbuf[p & 1];
+      a.users_out = out_final ? h->it.idx : ut;
+      a.vals_out = !h->u.val ? nullptr : (out_final ? h->it.val : vt);
+      a.offsets = counts; a.nnz = nnz; a.ntiles = ntiles; a.shift = p * RADIX_BITS;
+      hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(256), 0, h->stream, a.keys_in, nnz, a.shift, ntiles, counts);
+      if ((rc = check_launch(h, "radix_count_kernel"))) break;
+      if ((rc = device_scan<uint64_t>(h, counts, ntiles * RADIX_DIGITS, counts, false))) break;
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, h->stream, a);
+      rc = check_launch(h, "radix_scatter_kernel");
+    }
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "CSC build failed on the device"; rc = HPF_ERR_HIP; }
+  } while (0);
+  dfree(cnt); dfree(bad); dfree(kbuf[0]); dfree(kbuf[1]); dfree(ut); dfree(vt); dfree(counts);
+  return rc;
 }
 
 // host digamma for the xi/eta Elog export (same series as the device one)
@@ -622,6 +855,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
 // user-side half of the iteration.
 // events: 0 start | 1 phi_item kernel done | 2 its combine done |
 //         3 phi_user kernel done | 4 its combine done | 5 user sweep | 6 item sweep
+//         7 start of the replicated half (after whatever exchange the stream waited for)
 int phi_items(hpf_handle *h)
 {
   int rc;
@@ -688,6 +922,7 @@ int iterate_global(hpf_handle *h)
   int rc;
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
   if (!h->capturing && h->phase != 3) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
+  if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
   if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
   if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
@@ -791,8 +1026,9 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.n_users_total == 0) h->cfg.n_users_total = cfg->n_users;
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
-  h->w32 = cfg->w_storage == 1;
-  if (const char *e = getenv("HPF_W_STORAGE")) h->w32 = !strcmp(e, "f32") || !strcmp(e, "1");
+  h->w32 = cfg->w_storage == 1;          // only ever chosen by the caller's hpf_config
+  if (const char *e = getenv("HPF_H2D")) h->xfer_mode = !strcmp(e, "plain") ? 0 : !strcmp(e, "register") ? 2 : 1;
+  if (const char *e = getenv("HPF_H2D_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) h->xfer_threads = (unsigned)v; }
   if (cfg->w_storage > 1) { delete h; return HPF_ERR_INVALID; }
   // 16-byte rows of W: 2 doubles or 4 floats
   h->K = cfg->K; h->C = C; h->ld = h->w32 ? (C + 3u) & ~3u : (C + 1u) & ~1u;
@@ -804,7 +1040,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     h->own_stream = true;
   }
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
-    for (int e = 0; e < 7; ++e)
+    for (int e = 0; e < 8; ++e)
       if (hipEventCreate(&h->evr[r][e]) != hipSuccess) return fail(HPF_ERR_HIP);
 
   // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
@@ -911,9 +1147,13 @@ void hpf_destroy(hpf_handle *h)
   free_side(h->it, true);
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
-  dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->flags);
+  dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->colptr_dev); dfree(h->flags);
+  for (int k = 0; k < 2; ++k) {
+    if (h->stage[k]) (void)hipHostFree(h->stage[k]);
+    if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
+  }
   for (uint32_t r = 0; r < hpf_handle::RING; ++r)
-    for (int e = 0; e < 7; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
+    for (int e = 0; e < 8; ++e) if (h->evr[r][e]) (void)hipEventDestroy(h->evr[r][e]);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -979,7 +1219,7 @@ int hpf_allreduce_exchange(hpf_handle *h)
   if (!h->items_reduce_pending) {               // everything at once, on the stream the kernels use
     const int rc = g_rccl.AllReduce(h->exch, h->exch, h->exch_count, 8, 0, h->comm, (void *)h->stream);
     if (rc != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc); return HPF_ERR_HIP; }
-    return HPF_OK;
+    return check_comm_async(h);
   }
   // the item part is already on its way: add the [ld] tail (sum_u E[theta]), then
   // let the kernels' stream wait for both
@@ -992,7 +1232,7 @@ int hpf_allreduce_exchange(hpf_handle *h)
   HIPCHK(h, hipEventRecord(h->ev_reduced, h->comm_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_reduced, 0));
   h->items_reduce_pending = false;
-  return HPF_OK;
+  return check_comm_async(h);
 }
 
 int hpf_exchange_read(hpf_handle *h, double *host, size_t count)
@@ -1018,74 +1258,88 @@ int hpf_exchange_buffer(hpf_handle *h, void **dev, size_t *count)
   return HPF_OK;
 }
 
-int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, const uint8_t *val)
+// common tail of both uploads: h->u.idx / h->u.val / h->rowptr_dev are in place
+static int finish_upload(hpf_handle *h, const int64_t *rowptr /* host */, uint64_t nnz)
 {
-  if (!h || !rowptr) return HPF_ERR_INVALID;
   const uint32_t n = h->u.rows, m = h->it.rows;
-  drop_graph(h);
+  int rc;
+  if ((rc = build_csc_device(h, n, m, nnz))) return rc;
+  std::vector<int64_t> colptr((size_t)m + 1, 0);
+  if ((rc = d2h(h, colptr.data(), h->colptr_dev, ((size_t)m + 1) * 8))) return rc;
+  if ((uint64_t)colptr[m] != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
+  if ((rc = upload_side_work(h, h->u, rowptr, n, nnz, colptr.data(), m))) return rc;
+  if ((rc = upload_side_work(h, h->it, colptr.data(), m, nnz, rowptr, n))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->nnz = nnz; h->have_csr = true;
+  return HPF_OK;
+}
+
+static int check_rowptr(hpf_handle *h, const int64_t *rowptr, uint32_t n)
+{
   if (rowptr[0] != 0) { h->err = "rowptr[0] must be 0"; return HPF_ERR_INVALID; }
   for (uint32_t r = 0; r < n; ++r)
     if (rowptr[r + 1] < rowptr[r]) { h->err = "rowptr not monotone"; return HPF_ERR_INVALID; }
+  return HPF_OK;
+}
+
+static int alloc_user_nonzeros(hpf_handle *h, uint64_t nnz, bool with_val)
+{
+  int rc;
+  drop_graph(h);
+  h->have_csr = false;
+  dfree(h->u.idx); dfree(h->u.val); h->u.idx = nullptr; h->u.val = nullptr;
+  dfree(h->rowptr_dev); h->rowptr_dev = nullptr;
+  if ((rc = dalloc(h, &h->u.idx, (size_t)nnz))) return rc;
+  if (with_val && (rc = dalloc(h, &h->u.val, (size_t)nnz))) return rc;
+  return dalloc(h, &h->rowptr_dev, (size_t)h->u.rows + 1);
+}
+
+int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, const uint8_t *val)
+{
+  if (!h || !rowptr) return HPF_ERR_INVALID;
+  const uint32_t n = h->u.rows;
+  int rc;
+  if ((rc = check_rowptr(h, rowptr, n))) return rc;
   const uint64_t nnz = (uint64_t)rowptr[n];
   if (nnz && !col) return HPF_ERR_INVALID;
-  // item-major view: counting sort by item keeps users ascending inside an
-  // item, i.e. the order in which the reference's serial loop reaches them.
-  // Host threads each take a contiguous user range of ~nnz/T nonzeros: private
-  // histograms, then offsets = colptr[item] + (count in the earlier ranges), then
-  // a private scatter -- the result is the serial counting sort's, bit for bit.
-  unsigned T = std::thread::hardware_concurrency();
-  if (const char *e = getenv("HPF_UPLOAD_THREADS")) T = (unsigned)atoi(e);
-  T = std::max(1u, std::min(T, 64u));
-  if (nnz < (4u << 20)) T = 1;
-  while (T > 1 && (uint64_t)T * m > (1ull << 30)) T /= 2;          // <= 4 GiB of counters
-  std::vector<uint32_t> ucut(T + 1, n);
-  ucut[0] = 0;
-  for (unsigned t = 1; t < T; ++t)
-    ucut[t] = (uint32_t)(std::lower_bound(rowptr, rowptr + n + 1, (int64_t)(nnz / T * t)) - rowptr);
-  for (unsigned t = 1; t <= T; ++t) ucut[t] = std::max(ucut[t], ucut[t - 1]);
-  std::vector<std::vector<uint32_t>> cnt(T);
-  std::vector<int> bad(T, 0);
-  auto run = [&](auto &&fn) {
-    if (T == 1) { fn(0u); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
-    for (auto &x : th) x.join();
-  };
-  run([&](unsigned t) {
-    std::vector<uint32_t> &c = cnt[t];
-    c.assign(m, 0);
-    for (int64_t j = rowptr[ucut[t]]; j < rowptr[ucut[t + 1]]; ++j) {
-      if (col[j] >= m) { bad[t] = 1; return; }
-      c[col[j]]++;
-    }
-  });
-  for (unsigned t = 0; t < T; ++t) if (bad[t]) { h->err = "item index out of range"; return HPF_ERR_INVALID; }
-  std::vector<int64_t> colptr((size_t)m + 1, 0);
-  for (uint32_t i = 0; i < m; ++i) {
-    uint32_t before = 0;
-    for (unsigned t = 0; t < T; ++t) { const uint32_t c = cnt[t][i]; cnt[t][i] = before; before += c; }
-    colptr[i + 1] = colptr[i] + before;
-  }
-  std::vector<uint32_t> cuser((size_t)nnz);
-  std::vector<uint8_t> cval(val ? (size_t)nnz : 0);
-  run([&](unsigned t) {
-    std::vector<uint32_t> &rel = cnt[t];
-    for (uint32_t u = ucut[t]; u < ucut[t + 1]; ++u)
-      for (int64_t j = rowptr[u]; j < rowptr[u + 1]; ++j) {
-        const int64_t p = colptr[col[j]] + rel[col[j]]++;
-        cuser[(size_t)p] = u;
-        if (val) cval[(size_t)p] = val[j];
-      }
-  });
-  cnt.clear();
+  if ((rc = alloc_user_nonzeros(h, nnz, val != nullptr))) return rc;
+  if ((rc = h2d(h, h->u.idx, col, nnz * 4))) return rc;
+  if (val && (rc = h2d(h, h->u.val, val, nnz))) return rc;
+  if ((rc = h2d(h, h->rowptr_dev, rowptr, ((size_t)n + 1) * 8))) return rc;
+  return finish_upload(h, rowptr, nnz);
+}
+
+int hpf_upload_csr_device(hpf_handle *h, const int64_t *d_rowptr, const uint32_t *d_col, const uint8_t *d_val)
+{
+  if (!h || !d_rowptr) return HPF_ERR_INVALID;
+  const uint32_t n = h->u.rows;
   int rc;
-  if ((rc = upload_side_work(h, h->u, rowptr, n, col, val, nnz, colptr.data(), m))) return rc;
-  if ((rc = upload_side_work(h, h->it, colptr.data(), m, cuser.data(), val ? cval.data() : nullptr, nnz, rowptr, n))) return rc;
-  dfree(h->rowptr_dev); h->rowptr_dev = nullptr;
-  if ((rc = dalloc(h, &h->rowptr_dev, (size_t)n + 1))) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->rowptr_dev, rowptr, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  std::vector<int64_t> rowptr((size_t)n + 1);
+  if ((rc = d2h(h, rowptr.data(), d_rowptr, ((size_t)n + 1) * 8))) return rc;
+  if ((rc = check_rowptr(h, rowptr.data(), n))) return rc;
+  const uint64_t nnz = (uint64_t)rowptr[n];
+  if (nnz && !d_col) return HPF_ERR_INVALID;
+  if ((rc = alloc_user_nonzeros(h, nnz, d_val != nullptr))) return rc;
+  if (nnz) HIPCHK(h, hipMemcpyAsync(h->u.idx, d_col, nnz * 4, hipMemcpyDeviceToDevice, h->stream));
+  if (nnz && d_val) HIPCHK(h, hipMemcpyAsync(h->u.val, d_val, nnz, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->rowptr_dev, d_rowptr, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->nnz = nnz; h->have_csr = true;
+  return finish_upload(h, rowptr.data(), nnz);
+}
+
+int hpf_get_csc(hpf_handle *h, int64_t *colptr, uint32_t *users, uint8_t *vals)
+{
+  if (!h) return HPF_ERR_INVALID;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if (h->it.phases != 1) { h->err = "the item-major view is reordered by the hot/cold split"; return HPF_ERR_UNSUPPORTED; }
+  int rc;
+  if (colptr && (rc = d2h(h, colptr, h->colptr_dev, ((size_t)h->it.rows + 1) * 8))) return rc;
+  if (users && (rc = d2h(h, users, h->it.idx, (size_t)h->nnz * 4))) return rc;
+  if (vals) {
+    if (!h->it.val) { h->err = "no ratings were uploaded (-binary-data)"; return HPF_ERR_INVALID; }
+    if ((rc = d2h(h, vals, h->it.val, (size_t)h->nnz))) return rc;
+  }
   return HPF_OK;
 }
 
@@ -1105,13 +1359,25 @@ static int state_dims(const hpf_handle *h, int which, Side **side, uint32_t *row
   return -1;
 }
 
-int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t count)
+// on_device: `host` is a device pointer (hpf_set_state_device)
+static int set_state_impl(hpf_handle *h, hpf_state which, const double *host, size_t count, bool on_device)
 {
   if (!h || !host || which < 0 || which >= HPF_NUM_STATE) return HPF_ERR_INVALID;
   Side *s; uint32_t rows, cols; int col0, kind;
   if (state_dims(h, which, &s, &rows, &cols, &col0, &kind)) { h->err = "state not part of this model"; return HPF_ERR_INVALID; }
   const int obj = which / 4;
   int rc;
+  auto put = [&](void *dst, const void *src, size_t bytes) -> int {
+    if (!on_device) return h2d(h, dst, src, bytes);
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  };
+  auto put2d = [&](double *dev, uint32_t c0) -> int {
+    return on_device ? copy_in_dev(h, dev, h->ld, c0, host, rows, cols) : copy_in(h, dev, h->ld, c0, host, rows, cols);
+  };
+  // a new state supersedes whatever the kernels flagged about the old one
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
   if (obj == 2 || obj == 3) {                 // xi / eta vectors
     if (count != rows) return HPF_ERR_INVALID;
     double **dst = nullptr;
@@ -1122,9 +1388,7 @@ int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t cou
       default: dst = &s->prior_elog; break;
     }
     if (!*dst && (rc = dalloc(h, dst, rows))) return rc;
-    HIPCHK(h, hipMemcpyAsync(*dst, host, (size_t)rows * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return HPF_OK;
+    return put(*dst, host, (size_t)rows * 8);
   }
   const bool gr_rate = (obj <= 1 && kind == 1 && !h->cfg.hier);
   if (kind == 1) {                            // rate: kept only for export before iteration 0
@@ -1134,62 +1398,65 @@ int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t cou
     dfree(s->rate_set); s->rate_set = nullptr;
     if ((rc = dalloc(h, &s->rate_set, want))) return rc;
     s->rate_set_count = want;
-    HIPCHK(h, hipMemcpyAsync(s->rate_set, host, want * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return HPF_OK;
+    return put(s->rate_set, host, want * 8);
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
   if ((rc = refresh_es(h, *s))) return rc;     // the rest of S / E must be current before patching
   double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
-  if ((rc = copy_in(h, dev, h->ld, (uint32_t)col0, host, rows, cols))) return rc;
+  if (kind == 3 && s->l_stale) {
+    // the rest of L predates the last sweep: rebuild it before patching in the new part
+    if ((rc = refresh_elog(h, *s))) return rc;
+  }
+  if ((rc = put2d(dev, (uint32_t)col0))) return rc;
   if (obj <= 1) {
     if (kind == 2) s->have_E = true;
     if (kind == 3) s->have_L = true;
   }
-  if (kind == 3) {                           // Elog of theta/beta or of a bias column
-    if (s->l_stale) {
-      // the rest of L predates the last sweep: rebuild it before patching in the new part
-      int rc2 = refresh_elog(h, *s);
-      if (rc2) return rc2;
-      if ((rc = copy_in(h, dev, h->ld, (uint32_t)col0, host, rows, cols))) return rc;
-    }
-    s->w_dirty = true;
-  }
+  if (kind == 3) s->w_dirty = true;          // Elog of theta/beta or of a bias column
   if (kind != 0) h->derived_dirty = true;
   return HPF_OK;
 }
 
-int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
+int hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t count)
+{
+  return set_state_impl(h, which, host, count, false);
+}
+int hpf_set_state_device(hpf_handle *h, hpf_state which, const double *dev, size_t count)
+{
+  return set_state_impl(h, which, dev, count, true);
+}
+
+static int get_state_impl(hpf_handle *h, hpf_state which, double *host, size_t count, bool on_device)
 {
   if (!h || !host || which < 0 || which >= HPF_NUM_STATE) return HPF_ERR_INVALID;
   Side *s; uint32_t rows, cols; int col0, kind;
   if (state_dims(h, which, &s, &rows, &cols, &col0, &kind)) { h->err = "state not part of this model"; return HPF_ERR_INVALID; }
   const int obj = which / 4;
   const double s0 = h->cfg.s_prior, r0 = h->cfg.r_prior;
+  auto get = [&](void *dst, const void *src, size_t bytes) -> int {
+    if (!on_device) return d2h(h, dst, src, bytes);
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  };
+  auto fill = [&](double v, size_t cnt) -> int {         // a constant vector
+    std::vector<double> tmp(cnt, v);
+    if (!on_device) { memcpy(host, tmp.data(), cnt * 8); return HPF_OK; }
+    HIPCHK(h, hipMemcpyAsync(host, tmp.data(), cnt * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  };
   if (obj == 2 || obj == 3) {
     if (count != rows) return HPF_ERR_INVALID;
-    if (kind == 2 || kind == 1) {
-      const double *src = kind == 2 ? s->prior_E : s->prior_rate;
-      HIPCHK(h, hipMemcpyAsync(host, src, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      return HPF_OK;
-    }
-    if (kind == 3) {                     // Elog: set by the host, then maintained by the sweep
-      HIPCHK(h, hipMemcpyAsync(host, s->prior_elog, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      return HPF_OK;
-    }
+    if (kind == 2 || kind == 1) return get(host, kind == 2 ? s->prior_E : s->prior_rate, (size_t)rows * 8);
+    if (kind == 3) return get(host, s->prior_elog, (size_t)rows * 8);   // set by the host, then maintained by the sweep
     if (h->iterations == 0) {
       const double *src = s->prior_shape_set;
       if (!src) { h->err = "state was never set"; return HPF_ERR_STATE; }
-      HIPCHK(h, hipMemcpyAsync(host, src, (size_t)rows * 8, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      return HPF_OK;
+      return get(host, src, (size_t)rows * 8);
     }
     // after a sweep: shape = s0 + K*s0 (gpbase.hh:877-882)
-    const double sh = s0 + (double)h->K * s0;
-    for (uint32_t r = 0; r < rows; ++r) host[r] = sh;
-    return HPF_OK;
+    return fill(s0 + (double)h->K * s0, rows);
   }
   if (kind == 1) {                            // rate
     const bool gr = (obj <= 1 && !h->cfg.hier);
@@ -1197,40 +1464,49 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
     if (count != want) return HPF_ERR_INVALID;
     if (obj >= 4) {                           // gpbase.hh:225-231 via hgaprec.cc:1389,1393
       if (h->iterations == 0) { h->err = "bias rate is defined after the first sweep"; return HPF_ERR_STATE; }
-      for (uint32_t r = 0; r < rows; ++r) host[r] = r0 + s->bias_rate_add;
-      return HPF_OK;
+      return fill(r0 + s->bias_rate_add, rows);
     }
     if (h->iterations == 0) {
       if (!s->rate_set || s->rate_set_count != want) { h->err = "state was never set"; return HPF_ERR_STATE; }
-      HIPCHK(h, hipMemcpyAsync(host, s->rate_set, want * 8, hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      return HPF_OK;
+      return get(host, s->rate_set, want * 8);
     }
     if (gr) {                                 // r_k = 0.3 + colsum_k  (gpbase.hh:558-562)
       std::vector<double> cs(h->ld);
       HIPCHK(h, hipMemcpyAsync(cs.data(), s->colsum_used, (size_t)h->ld * 8, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
-      for (uint32_t k = 0; k < h->K; ++k) host[k] = r0 + cs[k];
+      for (uint32_t k = 0; k < h->K; ++k) cs[k] += r0;
+      if (!on_device) { memcpy(host, cs.data(), (size_t)h->K * 8); return HPF_OK; }
+      HIPCHK(h, hipMemcpyAsync(host, cs.data(), (size_t)h->K * 8, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
       return HPF_OK;
     }
-    double *tmp = nullptr; int rc;
-    if ((rc = dalloc(h, &tmp, want))) return rc;
+    double *tmp = on_device ? host : nullptr; int rc = HPF_OK;
+    if (!on_device && (rc = dalloc(h, &tmp, want))) return rc;
     hipLaunchKernelGGL(build_rate_kernel, dim3(1024), dim3(256), 0, h->stream, s->prior_used,
                        s->colsum_used, rows, h->K, tmp);
     rc = check_launch(h, "build_rate");
     if (!rc) {
-      hipError_t e = hipMemcpyAsync(host, tmp, want * 8, hipMemcpyDeviceToHost, h->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-      if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; }
+      if (on_device) { if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "build_rate failed"; rc = HPF_ERR_HIP; } }
+      else rc = d2h(h, host, tmp, want * 8);
     }
-    dfree(tmp);
+    if (!on_device) dfree(tmp);
     return rc;
   }
   if (count != (size_t)rows * cols) return HPF_ERR_INVALID;
   { int rc = check_flags(h); if (rc) return rc; }
   { int rc = kind == 3 ? refresh_elog(h, *s) : refresh_es(h, *s); if (rc) return rc; }
   const double *dev = kind == 0 ? s->S : kind == 2 ? s->E : s->L;
-  return copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
+  return on_device ? copy_out_dev(h, dev, h->ld, (uint32_t)col0, host, rows, cols)
+                   : copy_out(h, dev, h->ld, (uint32_t)col0, host, rows, cols);
+}
+
+int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
+{
+  return get_state_impl(h, which, host, count, false);
+}
+int hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t count)
+{
+  return get_state_impl(h, which, dev, count, true);
 }
 
 int hpf_iterate(hpf_handle *h, int n_iters)
@@ -1515,6 +1791,24 @@ int hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel, const u
   return rc;
 }
 
+int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
+{
+  if (!h || !out) return HPF_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->nnz = h->nnz;
+  out->user_segments = h->u.nseg[0] + h->u.nseg[1];
+  out->user_long_rows = h->u.nlong[0] + h->u.nlong[1] + h->u.nhuge[0] + h->u.nhuge[1];
+  out->user_huge_rows = h->u.nhuge[0] + h->u.nhuge[1];
+  out->item_segments = h->it.nseg[0] + h->it.nseg[1];
+  out->item_long_rows = h->it.nlong[0] + h->it.nlong[1] + h->it.nhuge[0] + h->it.nhuge[1];
+  out->item_huge_rows = h->it.nhuge[0] + h->it.nhuge[1];
+  out->phi_G = (uint32_t)h->phiG; out->phi_R = (uint32_t)h->phiR; out->phi_V = (uint32_t)h->phiV;
+  out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;
+  out->ld = h->ld;
+  out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
+  return HPF_OK;
+}
+
 int hpf_synchronize(hpf_handle *h)
 {
   if (!h) return HPF_ERR_INVALID;
@@ -1529,16 +1823,19 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
   uint32_t n = std::min<uint32_t>(std::min<uint32_t>(n_last, h->ev_count), hpf_handle::RING);
   if (n == 0) return HPF_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t slot = (h->ev_count - 1 - k) % hpf_handle::RING;
     hipEvent_t *ev = h->evr[slot];
-    float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // a graph-replayed iteration is one launch: only its total is known
-    if (!h->ring_graphed[slot])
-      for (int j = 0; j < 6; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
+    if (!h->ring_graphed[slot]) {
+      for (int j = 0; j < 5; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
+      HIPCHK(h, hipEventElapsedTime(&ms[7], ev[5], ev[7]));      // exchange the stream waited for
+      HIPCHK(h, hipEventElapsedTime(&ms[5], ev[7], ev[6]));      // the item sweep itself
+    }
     HIPCHK(h, hipEventElapsedTime(&ms[6], ev[0], ev[6]));
-    for (int j = 0; j < 7; ++j) acc[j] += ms[j];
+    for (int j = 0; j < 8; ++j) acc[j] += ms[j];
   }
   out->phi_item_ms = (float)(acc[0] / n);
   out->combine_item_ms = (float)(acc[1] / n);
@@ -1547,6 +1844,7 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
   out->sweep_user_ms = (float)(acc[4] / n);
   out->sweep_item_ms = (float)(acc[5] / n);
   out->iteration_ms = (float)(acc[6] / n);
+  out->exchange_wait_ms = (float)(acc[7] / n);
   return HPF_OK;
 }
 

@@ -1,9 +1,15 @@
 """Synthetic sparse rating matrices -- generator G(seed, n, m, nnz, alpha_u, alpha_i)
 of SURVEY.md section 8(d), and the bench-mode initial state.
 
+Every random quantity is a pure function of (seed, user, draw index) or of
+(seed, user, item) through a counter hash (splitmix64), never of a stateful
+generator: any contiguous user range of the SAME matrix can therefore be
+produced on its own, on any device, by any rank -- which is what the strong-
+scaling bench needs (each rank builds only its shard of BASELINE config C3).
+
 Runs on whatever torch device it is given (the GPU in bench.py, the CPU in the
-tests); torch is plumbing here (sort / unique / searchsorted on 5e7 keys), the
-product path starts at hpf_upload_csr.
+tests); torch is plumbing here (sort / unique / searchsorted on 1e9 keys), the
+product path starts at hpf_upload_csr / hpf_upload_csr_device.
 """
 from __future__ import annotations
 
@@ -26,13 +32,56 @@ CONFIGS = {
                seed=20260905, hier=True, bias=False, binary=True),
 }
 
+CHUNK_DRAWS = 1_500_000_000        # the device sort behind torch.unique takes < 2^31 keys
 
-CHUNK_DRAWS = 1_500_000_000
+_M64 = (1 << 64) - 1
 
 
-def _degrees(n, m, nnz, alpha_u, gen, device):
+def _s64(x: int) -> int:
+    """python int -> the int64 with the same low 64 bits"""
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+_C1, _C2, _G = _s64(0xBF58476D1CE4E5B9), _s64(0x94D049BB133111EB), _s64(0x9E3779B97F4A7C15)
+
+
+def _lsr(x, k):
+    """logical shift right of an int64 tensor"""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _mix(x):
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic)"""
+    x = (x ^ _lsr(x, 30)) * _C1
+    x = (x ^ _lsr(x, 27)) * _C2
+    return x ^ _lsr(x, 31)
+
+
+def _hash(seed: int, a, b=None):
+    """64 well-mixed bits per element of the int64 tensor(s) a (, b)"""
+    x = _mix(a * _G + _s64(seed * 0x632BE59BD9B4E019 + 0x2545F4914F6CDD1D))
+    if b is not None:
+        x = _mix(x ^ (b * _C2 + _G))
+    return x
+
+
+def _u01(h):
+    """top 53 bits of a hash as a double in [0, 1)"""
+    return _lsr(h, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def _perm(n, seed, device):
+    """a permutation of 0..n-1 that depends only on (n, seed)"""
+    h = _hash(seed, torch.arange(n, dtype=torch.int64, device=device))
+    return torch.sort(h, stable=True)[1]
+
+
+def degrees(n, m, nnz, alpha_u, seed, device="cpu"):
     """power-law user degrees d_u ~ (rank+1)^-alpha_u, 1 <= d_u <= m/2,
-    sum(d) = nnz (when the caps allow), ranks randomly permuted"""
+    sum(d) = nnz (when the caps allow), ranks permuted by a hash of the seed;
+    int64[n], identical on every device / rank"""
+    device = torch.device(device)
     cap = max(1, m // 2)
     w = torch.arange(1, n + 1, dtype=torch.float64, device=device) ** (-alpha_u)
     t = w / w.sum() * nnz
@@ -49,7 +98,7 @@ def _degrees(n, m, nnz, alpha_u, gen, device):
                 d[idx] += torch.clamp(cap - d[idx], max=rem // idx.numel())
             else:
                 frac = (t - torch.floor(t))[idx]
-                d[idx[torch.argsort(frac, descending=True)[:rem]]] += 1
+                d[idx[torch.sort(frac, descending=True, stable=True)[1][:rem]]] += 1
         else:
             idx = torch.nonzero(d > 1, as_tuple=False).flatten()
             if idx.numel() == 0:
@@ -57,98 +106,119 @@ def _degrees(n, m, nnz, alpha_u, gen, device):
             if -rem >= idx.numel():
                 d[idx] -= torch.clamp(d[idx] - 1, max=(-rem) // idx.numel())
             else:
-                d[idx[torch.argsort(d[idx], descending=True)[:(-rem)]]] -= 1
-    perm = torch.randperm(n, generator=gen, device=device)
-    return d[perm]
+                d[idx[torch.sort(d[idx], descending=True, stable=True)[1][:(-rem)]]] -= 1
+    return d[_perm(n, seed, device)]
 
 
-def generate(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=False,
-             item_seed=None, topup_rounds=4):
-    """-> rowptr int64[n+1], col uint32[nnz'], val uint8[nnz'] (numpy, host).
-    Users get power-law degrees, items are drawn without replacement per user
-    from a power-law popularity (draw, dedupe, top up); columns sorted in a row.
-    item_seed fixes the item popularity permutation independently of `seed`
-    (multi-GPU: every rank shares the items, owns its users)."""
+def generate_device(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=False,
+                    item_seed=None, topup_rounds=4, user_range=None, deg=None):
+    """-> torch tensors on `device`: rowptr int64[b-a+1], col int32[nnz'],
+    val uint8[nnz'] | None for users [a, b) = user_range (default: all) of the
+    matrix G(seed, n, m, nnz, alpha_u, alpha_i).  Users get power-law degrees,
+    items are drawn without replacement per user from a power-law popularity
+    (draw, dedupe, top up); columns sorted inside a row; col holds item ids
+    < m < 2^31.  `deg` may pass in degrees(...) already computed."""
     device = torch.device(device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(seed))
-    igen = torch.Generator(device=device)
-    igen.manual_seed(int(seed if item_seed is None else item_seed) + 7919)
-    d = _degrees(n, m, nnz, alpha_u, gen, device)
+    a, b = (0, n) if user_range is None else (int(user_range[0]), int(user_range[1]))
+    d_all = degrees(n, m, nnz, alpha_u, seed, device) if deg is None else deg.to(device)
+    d = d_all[a:b]
+    del d_all
     p = torch.arange(1, m + 1, dtype=torch.float64, device=device) ** (-alpha_i)
     cdf = torch.cumsum(p / p.sum(), 0)
-    iperm = torch.randperm(m, generator=igen, device=device)
+    del p
+    iseed = int(seed if item_seed is None else item_seed) + 7919
+    iperm = _perm(m, iseed, device)
+    nloc = b - a
 
-    # users are processed in contiguous chunks of at most CHUNK_DRAWS draws (the
-    # device sort behind torch.unique takes < 2^31 keys); one chunk -- every
-    # configuration up to C3's 1e9 nonzeros -- is the unchunked algorithm
+    # users are processed in contiguous chunks of at most CHUNK_DRAWS draws
     cum = torch.cumsum(d, 0)
     bounds = [0]
-    while bounds[-1] < n:
+    while bounds[-1] < nloc:
         base = int(cum[bounds[-1] - 1]) if bounds[-1] > 0 else 0
         nxt = int(torch.searchsorted(cum, torch.tensor(base + CHUNK_DRAWS, device=device), right=True))
-        bounds.append(min(n, max(nxt, bounds[-1] + 1)))
-    counts = torch.zeros(n, dtype=torch.int64, device=device)
+        bounds.append(min(nloc, max(nxt, bounds[-1] + 1)))
+    del cum
+    counts = torch.zeros(nloc, dtype=torch.int64, device=device)
     cols, vals = [], []
-    pr = torch.tensor(RATING_P, dtype=torch.float64, device=device)
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        users = torch.arange(a, b, device=device, dtype=torch.int64)
+    thr = torch.cumsum(torch.tensor(RATING_P, dtype=torch.float64, device=device), 0)
+    for ca, cb in zip(bounds[:-1], bounds[1:]):
+        users = torch.arange(a + ca, a + cb, device=device, dtype=torch.int64)     # global user ids
         keys = torch.empty(0, dtype=torch.int64, device=device)
-        dc = d[a:b]
+        dc = d[ca:cb]
         need = dc.clone()
+        drawn = torch.zeros_like(dc)                       # draws made so far per user (the counter)
         for _ in range(topup_rounds):
             tot = int(need.sum())
             if tot == 0:
                 break
             u = torch.repeat_interleave(users, need)
-            r = torch.rand(tot, generator=gen, device=device, dtype=torch.float64)
+            first = torch.cumsum(need, 0) - need           # offset of each user's run
+            q = torch.arange(tot, device=device, dtype=torch.int64) - torch.repeat_interleave(first - drawn, need)
+            r = _u01(_hash(seed, u, q))
+            del q
             it = iperm[torch.searchsorted(cdf, r).clamp(max=m - 1)]
+            del r
             keys = torch.unique(torch.cat([keys, u * m + it]))
-            del u, r, it
-            have = torch.bincount(keys // m - a, minlength=b - a)
+            del u, it
+            drawn = drawn + need
+            have = torch.bincount(keys // m - (a + ca), minlength=cb - ca)
             need = (dc - have).clamp(min=0)
-        counts[a:b] = torch.bincount(keys // m - a, minlength=b - a)
-        cols.append((keys % m).to(torch.int32).cpu().numpy().view(np.uint32))
+        counts[ca:cb] = torch.bincount(keys // m - (a + ca), minlength=cb - ca)
+        cols.append((keys % m).to(torch.int32))
         if not binary:
-            vals.append((torch.multinomial(pr, keys.numel(), replacement=True, generator=gen) + 1)
-                        .to(torch.uint8).cpu().numpy())
+            rr = _u01(_hash(seed + 104723, keys))          # rating = f(seed, user, item)
+            vals.append((torch.searchsorted(thr, rr).clamp(max=len(RATING_P) - 1) + 1).to(torch.uint8))
+            del rr
         del keys
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr = torch.zeros(nloc + 1, dtype=torch.int64, device=device)
     rowptr[1:] = torch.cumsum(counts, 0)
-    rp = rowptr.cpu().numpy()
-    c = cols[0] if len(cols) == 1 else np.concatenate(cols)
-    v = None if binary else (vals[0] if len(vals) == 1 else np.concatenate(vals))
-    return rp, c, v
+    col = cols[0] if len(cols) == 1 else torch.cat(cols)
+    val = None if binary else (vals[0] if len(vals) == 1 else torch.cat(vals))
+    return rowptr, col, val
+
+
+def generate(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=False,
+             item_seed=None, topup_rounds=4, user_range=None):
+    """generate_device(...) copied to the host: rowptr int64, col uint32, val uint8 | None (numpy)"""
+    rp, c, v = generate_device(n, m, nnz, alpha_u, alpha_i, seed, device, binary, item_seed,
+                               topup_rounds, user_range)
+    return rp.cpu().numpy(), c.cpu().numpy().view(np.uint32), None if v is None else v.cpu().numpy()
 
 
 def heldout(n, m, cnt, seed, device="cpu", binary=False):
     """cnt held-out pairs, sorted by (user, item) like std::map<Rating,int>"""
     device = torch.device(device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(seed) + 104729)
-    keys = torch.unique(torch.randint(0, n * m, (cnt,), generator=gen, device=device, dtype=torch.int64))
-    pr = torch.tensor(RATING_P, dtype=torch.float64, device=device)
-    y = (torch.multinomial(pr, keys.numel(), replacement=True, generator=gen) + 1).to(torch.int32)
+    idx = torch.arange(cnt, dtype=torch.int64, device=device)
+    keys = torch.unique(_lsr(_hash(seed + 104729, idx), 1) % (n * m))
+    thr = torch.cumsum(torch.tensor(RATING_P, dtype=torch.float64, device=device), 0)
+    y = (torch.searchsorted(thr, _u01(_hash(seed + 15485863, keys))).clamp(max=len(RATING_P) - 1) + 1).to(torch.int32)
     if binary:
         y = torch.ones_like(y)
     return ((keys // m).cpu().numpy().astype(np.uint32), (keys % m).cpu().numpy().astype(np.uint32),
             y.cpu().numpy())
 
 
-def initial_state(rows, K, seed, device="cpu", prior_v=None):
+def initial_state_device(rows, K, seed, device="cpu", prior_v=None, row0=0):
     """bench-mode start (no parity claim -- the parity path draws MT19937 on the
     host): shape = 0.3 + 0.01 U, E = shape / (0.3 + 0.1 U'), Elog = psi(shape) -
-    log(rate).  prior_v: returns the xi/eta style vector start instead
-    (shape 0.3 + 0.01 U, rate 0.3 + prior_v)."""
+    log(rate), U and U' hashes of (seed, global row, column).  prior_v: the
+    xi/eta style vector start instead (shape 0.3 + 0.01 U, rate 0.3 + prior_v).
+    Rows [row0, row0 + rows) of the full array: shards of one state agree.
+    -> dict of float64 torch tensors on `device`."""
     device = torch.device(device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(int(seed))
+    r = torch.arange(row0, row0 + rows, dtype=torch.int64, device=device)
     if prior_v is not None:
-        s = 0.3 + 0.01 * torch.rand(rows, generator=gen, device=device, dtype=torch.float64)
-        r = torch.full_like(s, 0.3 + float(prior_v))
+        s = 0.3 + 0.01 * _u01(_hash(seed, r))
+        rt = torch.full_like(s, 0.3 + float(prior_v))
     else:
-        s = 0.3 + 0.01 * torch.rand(rows, K, generator=gen, device=device, dtype=torch.float64)
-        r = 0.3 + 0.1 * torch.rand(rows, K, generator=gen, device=device, dtype=torch.float64)
-    e = s / r
-    el = torch.special.digamma(s) - torch.log(r)
-    return dict(shape=s.cpu().numpy(), rate=r.cpu().numpy(), E=e.cpu().numpy(), Elog=el.cpu().numpy())
+        e = r[:, None] * K + torch.arange(K, dtype=torch.int64, device=device)[None, :]
+        s = 0.3 + 0.01 * _u01(_hash(seed, e))
+        rt = 0.3 + 0.1 * _u01(_hash(seed + 1_000_003, e))
+        del e
+    return dict(shape=s, rate=rt, E=s / rt, Elog=torch.special.digamma(s) - torch.log(rt))
+
+
+def initial_state(rows, K, seed, device="cpu", prior_v=None, row0=0):
+    """initial_state_device(...) as numpy arrays on the host"""
+    st = initial_state_device(rows, K, seed, device, prior_v, row0)
+    return {k: v.cpu().numpy() for k, v in st.items()}

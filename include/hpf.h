@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 2
+#define HPF_ABI_VERSION 3
 
 typedef struct hpf_handle hpf_handle;
 
@@ -93,8 +93,7 @@ typedef struct {
 } hpf_config;
 
 /* per-kernel device time, milliseconds, from hipEvents recorded on the
- * handle's stream around each launch group (in multi-rank use sweep_item_ms
- * also spans the caller's all-reduce between iterate_local and _global) */
+ * handle's stream around each launch group */
 typedef struct {
   float phi_user_ms;     /* K1a: phi_pass_kernel<..,0>, user-major (theta sums) */
   float combine_user_ms; /*      combine of long user rows                      */
@@ -104,6 +103,9 @@ typedef struct {
   float sweep_item_ms;   /* K3 + K4(eta) + K5(item bias) + K7                   */
   float iteration_ms;    /* first launch -> last launch of the iteration        */
   uint32_t iterations;   /* iterations executed so far                          */
+  float exchange_wait_ms;/* end of the user sweep -> start of the item sweep:   */
+                         /* the part of the all-reduce the stream had to wait   */
+                         /* for (n_ranks > 1; ~0 on one rank)                   */
 } hpf_timing;
 
 int  hpf_abi_version(void);
@@ -121,9 +123,22 @@ void hpf_destroy(hpf_handle *h);
  * CSR over this handle's users in the reference's visiting order; col = item
  * seq id; val = rating as stored by the reference (uint8, already wrapped,
  * last duplicate wins), NULL => every rating is 1 (-binary-data).
- * Host pointers.  Builds the item-major (CSC) view and work lists on device. */
+ * Host pointers (staged through pinned buffers).  The item-major (CSC) view is
+ * built in HBM by a stable radix sort on the item id: inside an item the users
+ * stay ascending -- the order in which the reference's serial loop
+ * (hgaprec.cc:1340-1345) reaches them. */
 int  hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col,
                     const uint8_t *val);
+/* the same for a CSR that already lives in HBM (DEVICE pointers on the handle's
+ * device; the library copies what it keeps, the caller may free on return).
+ * The producer's work must have completed before the call. */
+int  hpf_upload_csr_device(hpf_handle *h, const int64_t *d_rowptr, const uint32_t *d_col,
+                           const uint8_t *d_val);
+/* replaces: the per-item user lists Ratings keeps beside the per-user ones
+ * (Ratings::get_users, ratings.hh:167-173): host copies of the item-major view
+ * (colptr[n_items + 1], users[nnz] ascending inside an item, vals[nnz]); any
+ * pointer may be NULL. */
+int  hpf_get_csc(hpf_handle *h, int64_t *colptr, uint32_t *users, uint8_t *vals);
 
 /* replaces: the result of HGAPRec::initialize (hgaprec.cc:153-204) -- the host
  * draws the MT19937 stream and hands over E / Elog (and shapes, for export).
@@ -132,6 +147,10 @@ int  hpf_set_state(hpf_handle *h, hpf_state which, const double *host, size_t co
 /* replaces: reads of shape_curr()/rate_curr()/expected_v()/expected_logv()
  * by save_model (hgaprec.cc:2137-2158) */
 int  hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count);
+/* the same with DEVICE pointers (dense row-major doubles in HBM, same element
+ * counts): no PCIe round trip for callers whose state is already resident */
+int  hpf_set_state_device(hpf_handle *h, hpf_state which, const double *dev, size_t count);
+int  hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t count);
 
 /* replaces: n_iters passes of steps A-F of HGAPRec::vb_hier
  * (hgaprec.cc:1340-1414), or of vb (927-956) / vb_bias (1226-1272) without
@@ -231,6 +250,22 @@ int  hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel,
                     const uint64_t *mask_ptr, const uint32_t *mask_items,
                     const uint32_t *q_sel, const uint32_t *q_item, uint32_t nq,
                     uint32_t *out_rank, double *out_score);
+
+/* how the uploaded matrix was cut into work (diagnostics, tests, bench):
+ * a "segment" is <= 512 consecutive nonzeros of one row; rows longer than that
+ * are "long" (their segment sums are combined by a second kernel) and rows with
+ * more than 256 segments "huge" (combined in two levels). */
+typedef struct {
+  uint64_t nnz;
+  uint32_t user_segments, user_long_rows, user_huge_rows;
+  uint32_t item_segments, item_long_rows, item_huge_rows;
+  uint32_t phi_G, phi_R, phi_V;      /* lanes per nonzero, loads per lane, doubles per load */
+  uint32_t sweep_G, sweep_R;
+  uint32_t ld;                       /* row stride of the device matrices, doubles */
+  uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
+  uint32_t reserved[3];
+} hpf_work_info;
+int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);

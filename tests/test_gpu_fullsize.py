@@ -9,6 +9,8 @@ iteration at this size:
  * xi update:  xi_rate == 0.3 + rowsum(E theta),  xi_shape == 0.3 + 0.3 K
  * user sharding: 2 logical ranks (host-summed exchange) == 1 rank to 1e-10
  * bit-identical repeat runs
+C3 (10M x 1M, 1e9 nnz) runs whole and C5 as the real shard one of 8 GPUs owns;
+both are generated, handed over and checked in HBM (hpf_upload_csr_device).
 """
 import ctypes as C
 
@@ -172,40 +174,185 @@ def test_c4_bias_k200_properties():
     D.close()
 
 
-def test_c5_shape_binary_k50_properties():
-    """BASELINE config C5's shape (-hier -binary-data, K=50, heavy-tailed
-    degrees alpha = 0.9 / 1.1) at 1/50 of its size (one GPU's share of a
-    50-GPU run: 1M x 40K, ~1e8 nnz): every nonzero is a 1, phi sums to 1."""
+def _device_model(cfg, n_loc, rowptr, col, val, row0, n_total, n_ranks=1, rank=0, xbuf=None, seeds=(1, 2, 3, 4)):
+    """a handle fed entirely from HBM: hpf_upload_csr_device + hpf_set_state_device;
+    rows [row0, row0 + n_loc) of the hashed bench-mode start state"""
     import torch
     from hgaprec_amd import synth
     from hgaprec_amd.capi import Hpf
-    cfg = dict(synth.CONFIGS["C5"])
-    n, m, nnz, K = cfg["n"] // 50, cfg["m"] // 50, cfg["nnz"] // 50, cfg["K"]
-    dev = torch.device("cuda", 0)
-    rowptr, col, val = synth.generate(n, m, nnz, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev,
-                                      binary=True)
-    assert val is None
-    D = Hpf(n, m, K, hier=True, binary=True)
-    D.upload_csr(rowptr, col, None)
-    st = synth.initial_state(n, K, 1, dev)
-    D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
-    st = synth.initial_state(m, K, 2, dev)
-    D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
-    D.set_state("XI_E", synth.initial_state(n, K, 3, dev, prior_v=K)["E"])
-    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    dev = rowptr.device
+    m, K = cfg["m"], cfg["K"]
+    D = Hpf(n_loc, m, K, hier=True, binary=cfg["binary"], n_ranks=n_ranks, rank=rank, n_users_total=n_total)
+    if xbuf is not None:
+        D.bind_exchange_buffer(xbuf.data_ptr(), xbuf.numel())
+    D.upload_csr_device(rowptr, col, val)
+    st = synth.initial_state_device(n_loc, K, seeds[0], dev, row0=row0)
+    D.set_state_device("THETA_E", st["E"]); D.set_state_device("THETA_ELOG", st["Elog"])
+    st = synth.initial_state_device(m, K, seeds[1], dev)
+    D.set_state_device("BETA_E", st["E"]); D.set_state_device("BETA_ELOG", st["Elog"])
+    D.set_state_device("XI_E", synth.initial_state_device(n_loc, K, seeds[2], dev, prior_v=K, row0=row0)["E"])
+    D.set_state_device("ETA_E", synth.initial_state_device(m, K, seeds[3], dev, prior_v=K)["E"])
     del st
     torch.cuda.empty_cache()
-    D.iterate(2)
-    ts, bs = D.get_state("THETA_SHAPE"), D.get_state("BETA_SHAPE")
-    mass = float(rowptr[-1])
-    assert abs((ts - 0.3).sum() - mass) / mass < 1e-11
-    assert abs((bs - 0.3).sum() - mass) / mass < 1e-11
-    deg_u = np.diff(rowptr).astype(np.float64)
-    assert np.max(np.abs((ts - 0.3).sum(1) - deg_u) / np.maximum(deg_u, 1.0)) < 1e-11
-    deg_i = np.bincount(col, minlength=m).astype(np.float64)
-    assert np.max(np.abs((bs - 0.3).sum(1) - deg_i) / np.maximum(deg_i, 1.0)) < 1e-11
+    return D
+
+
+def _row_mass(rowptr, w):
+    """sum of w over each CSR row (torch, on device); w = None counts nonzeros"""
+    import torch
+    if w is None:
+        return (rowptr[1:] - rowptr[:-1]).to(torch.float64)
+    c = torch.zeros(w.numel() + 1, dtype=torch.float64, device=w.device)
+    torch.cumsum(w, 0, out=c[1:])
+    return c[rowptr[1:]] - c[rowptr[:-1]]
+
+
+def test_c3_whole_properties():
+    """BASELINE config C3 WHOLE on one GPU (10M x 1M, 1e9 nnz, K=100, -hier;
+    ~60 GB resident), everything handed over and checked in HBM:
+     * mass conservation per user and per item after each of 2 iterations
+       (every nonzero's phi sums to its rating),
+     * the rate identity theta_rate[u,k] = E[xi_u] + sum_i E[beta_ik] and the
+       xi update xi_rate = 0.3 + rowsum(E theta) (hgaprec.cc:1370-1414),
+     * a second run gives identical bits,
+     * the same problem cut into 2 user shards by nnz (partition_users), their
+       exchange buffers summed, agrees with the single run to 1e-10."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.dist import partition_users
+    cfg = dict(synth.CONFIGS["C3"])
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate_device(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev)
+    torch.cuda.empty_cache()
+    nnz = int(rowptr[-1])
+    assert nnz > 0.99e9
+    w = torch.clamp(val, min=1).to(torch.float64)
+    mass_u = _row_mass(rowptr, w)
+    mass_i = torch.bincount(col.to(torch.int64), weights=w, minlength=m)
+    total = float(w.sum())
+    del w
+
+    def run(check):
+        D = _device_model(cfg, n, rowptr, col, val, 0, n)
+        xi0 = synth.initial_state_device(n, K, 3, dev, prior_v=K)["E"]
+        c0 = synth.initial_state_device(m, K, 2, dev)["E"].sum(0)
+        for it in range(2):
+            D.iterate(1)
+            if not check:
+                continue
+            ts = D.get_state_device("THETA_SHAPE", dev)
+            got_u = (ts - 0.3).sum(1)
+            assert float(((got_u - mass_u).abs() / mass_u.clamp(min=1.0)).max()) < 1e-11
+            assert abs(float(got_u.sum()) - total) / total < 1e-11
+            if it == 0:
+                tr = D.get_state_device("THETA_RATE", dev)
+                want = xi0[:, None] + c0[None, :]
+                assert float(((tr - want).abs() / want).max()) < 1e-12
+                te = D.get_state_device("THETA_E", dev)
+                assert float(((te - ts / tr).abs() / te).max()) < 1e-15
+                xr = D.get_state_device("XI_RATE", dev)
+                assert float(((xr - (0.3 + te.sum(1))).abs() / xr).max()) < 1e-13
+                del tr, want, te, xr
+            del ts, got_u
+            bs = D.get_state_device("BETA_SHAPE", dev)
+            got_i = (bs - 0.3).sum(1)
+            assert float(((got_i - mass_i).abs() / mass_i.clamp(min=1.0)).max()) < 1e-11
+            del bs, got_i
+        wi = D.work_info()
+        tm = D.mean_timing(1)
+        out = (D.get_state_device("THETA_E", dev), D.get_state_device("BETA_E", dev))
+        D.close()
+        torch.cuda.empty_cache()
+        return out, wi, tm
+
+    (te1, be1), wi, tm = run(True)
+    assert wi["nnz"] == nnz and wi["item_long_rows"] > 0
+    print(f"C3 whole: {nnz} nnz, {tm['iteration_ms']:.1f} ms/iteration "
+          f"(phi item {tm['phi_item_ms']:.1f}, phi user {tm['phi_user_ms']:.1f})")
+    (te2, be2), _, _ = run(False)
+    assert torch.equal(te1, te2) and torch.equal(be1, be2)
+    del te2, be2
+
+    parts = partition_users(rowptr.cpu().numpy(), 2)
+    shards, xb = [], []
+    for r, (a, b) in enumerate(parts):
+        lo, hi = int(rowptr[a]), int(rowptr[b])
+        x = torch.zeros((m + 1) * K, dtype=torch.float64, device=dev)       # [m x ld | ld], ld = K = 100
+        shards.append(_device_model(cfg, b - a, (rowptr[a:b + 1] - rowptr[a]).contiguous(), col[lo:hi], val[lo:hi],
+                                    a, n, 2, r, x))
+        xb.append(x)
+    assert abs((int(rowptr[parts[0][1]]) - nnz // 2)) < 4 * m                # balanced by nonzeros, not by users
+    for _ in range(2):
+        for S in shards:
+            S.iterate_local()
+        for S in shards:
+            S.synchronize()
+        tot = xb[0] + xb[1]
+        for S, x in zip(shards, xb):
+            x.copy_(tot)
+        torch.cuda.synchronize()
+        for S in shards:
+            S.iterate_global()
+    for (a, b), S in zip(parts, shards):
+        got = S.get_state_device("THETA_E", dev)
+        assert float(((got - te1[a:b]).abs() / te1[a:b]).max()) < 1e-10
+        gb = S.get_state_device("BETA_E", dev)
+        assert float(((gb - be1).abs() / be1).max()) < 1e-10
+        del got, gb
+        S.close()
+
+
+def test_c5_shard_full_size():
+    """BASELINE config C5 (50M x 2M, 5e9 nnz, K=50, -hier -binary-data,
+    heavy-tailed degrees alpha = 0.9 / 1.1): the REAL shard one of 8 GPUs owns --
+    the first of partition_users' 8 nnz-balanced user ranges of the whole matrix
+    (about 6.25M users, 6e8 nonzeros), all 2M items.  Blockbuster items are
+    rated by millions of the shard's users, so their rows take the two-level
+    combine (item_huge_rows > 0); per-user and per-item mass must still equal
+    the degrees exactly."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.dist import partition_users
+    cfg = dict(synth.CONFIGS["C5"])
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    dev = torch.device("cuda", 0)
+    deg = synth.degrees(n, m, cfg["nnz"], cfg["alpha_u"], cfg["seed"], dev)
+    planned = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=planned[1:])
+    a, b = partition_users(planned.cpu().numpy(), 8)[0]
+    del planned
+    rowptr, col, val = synth.generate_device(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"],
+                                             device=dev, binary=True, user_range=(a, b), deg=deg)
+    del deg
+    torch.cuda.empty_cache()
+    nnz = int(rowptr[-1])
+    assert val is None and 4.5e8 < nnz < 6.5e8 and 5_000_000 < b - a < 7_500_000
+    D = _device_model(cfg, b - a, rowptr, col, None, a, n, n_ranks=8, rank=0)
+    wi = D.work_info()
+    assert wi["item_huge_rows"] > 0, wi          # a blockbuster item: > 256 segments of 512 raters
+    assert wi["user_long_rows"] > 0, wi          # users at the m/2 degree cap
+    deg_u = _row_mass(rowptr, None)
+    deg_i = torch.bincount(col.to(torch.int64), minlength=m).to(torch.float64)
+    x = torch.zeros(1, device=dev)
+    for it in range(2):
+        D.iterate_local()
+        D.iterate_global()                       # this rank's sums only: a 1-of-8 shard run on its own
+        ts = D.get_state_device("THETA_SHAPE", dev)
+        assert float((((ts - 0.3).sum(1) - deg_u).abs() / deg_u.clamp(min=1.0)).max()) < 1e-11
+        del ts
+        bs = D.get_state_device("BETA_SHAPE", dev)
+        got = (bs - 0.3).sum(1)
+        assert float(((got - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
+        assert abs(float(got.sum()) - nnz) / nnz < 1e-11
+        del bs, got
+    tm = D.mean_timing(1)
+    print(f"C5 shard 0 of 8: users [{a}, {b}), {nnz} nnz, {wi['item_huge_rows']} huge item rows, "
+          f"{tm['iteration_ms']:.1f} ms/iteration (phi item {tm['phi_item_ms']:.1f} + combine "
+          f"{tm['combine_item_ms']:.2f}, phi user {tm['phi_user_ms']:.1f})")
     # held-out likelihood in its binary form: log(1 - exp(-s)) per pair, finite and negative
-    hu = np.arange(0, n, max(1, n // 5000), dtype=np.uint32)
+    nl = b - a
+    hu = np.arange(0, nl, max(1, nl // 5000), dtype=np.uint32)
     hi = (hu.astype(np.uint64) * 7919 % m).astype(np.uint32)
     s, c = D.heldout_ll(hu, hi, np.ones(hu.size, np.int32))
     assert c == hu.size and np.isfinite(s) and s < 0
@@ -215,32 +362,31 @@ def test_c5_shape_binary_k50_properties():
 def test_more_than_2_31_nonzeros():
     """64-bit indexing end to end: 4M users x 200K items with ~2.4e9 nonzeros
     (-binary-data, K=4 keeps the state small).  Per-user and per-item mass must
-    equal the degrees -- any 32-bit wrap in the work lists, the CSC build or the
-    kernels' nonzero offsets would break it."""
+    equal the degrees -- any 32-bit wrap in the work lists, the device CSC build
+    (radix tiles, scan) or the kernels' nonzero offsets would break it."""
     import torch
     from hgaprec_amd import synth
-    from hgaprec_amd.capi import Hpf
     n, m, nnz, K = 4_000_000, 200_000, 2_500_000_000, 4
     dev = torch.device("cuda", 0)
-    rowptr, col, val = synth.generate(n, m, nnz, 0.4, 0.7, seed=77, device=dev, binary=True)
+    rowptr, col, val = synth.generate_device(n, m, nnz, 0.4, 0.7, seed=77, device=dev, binary=True)
     torch.cuda.empty_cache()
     assert int(rowptr[-1]) > 2**31 and val is None
-    D = Hpf(n, m, K, hier=True, binary=True)
-    D.upload_csr(rowptr, col, None)
-    st = synth.initial_state(n, K, 1, dev)
-    D.set_state("THETA_E", st["E"]); D.set_state("THETA_ELOG", st["Elog"])
-    st = synth.initial_state(m, K, 2, dev)
-    D.set_state("BETA_E", st["E"]); D.set_state("BETA_ELOG", st["Elog"])
-    D.set_state("XI_E", synth.initial_state(n, K, 3, dev, prior_v=K)["E"])
-    D.set_state("ETA_E", synth.initial_state(m, K, 4, dev, prior_v=K)["E"])
+    cfg = dict(m=m, K=K, binary=True)
+    D = _device_model(cfg, n, rowptr, col, None, 0, n)
     D.iterate(2)
-    ts, bs = D.get_state("THETA_SHAPE"), D.get_state("BETA_SHAPE")
-    deg_u = np.diff(rowptr).astype(np.float64)
-    assert np.max(np.abs((ts - 0.3).sum(1) - deg_u) / np.maximum(deg_u, 1.0)) < 1e-11
-    deg_i = np.zeros(m, np.float64)
-    step = 1 << 28
-    for a in range(0, col.size, step):                      # bincount in slices: bounded host memory
-        deg_i += np.bincount(col[a:a + step], minlength=m)
-    assert np.max(np.abs((bs - 0.3).sum(1) - deg_i) / np.maximum(deg_i, 1.0)) < 1e-11
-    assert abs((ts - 0.3).sum() - float(rowptr[-1])) / float(rowptr[-1]) < 1e-11
+    ts, bs = D.get_state_device("THETA_SHAPE", dev), D.get_state_device("BETA_SHAPE", dev)
+    deg_u = _row_mass(rowptr, None)
+    assert float((((ts - 0.3).sum(1) - deg_u).abs() / deg_u.clamp(min=1.0)).max()) < 1e-11
+    deg_i = torch.zeros(m, dtype=torch.float64, device=dev)
+    step = 1 << 29
+    for a in range(0, col.numel(), step):                   # bincount in slices: bounded temporaries
+        deg_i += torch.bincount(col[a:a + step].to(torch.int64), minlength=m)
+    assert float((((bs - 0.3).sum(1) - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
+    assert abs(float((ts - 0.3).sum()) - float(rowptr[-1])) / float(rowptr[-1]) < 1e-11
+    # the item-major view itself, on a slice: users ascending inside each of the first items
+    colptr, users, _ = D.get_csc(int(rowptr[-1]), with_vals=False)
+    assert colptr[-1] == int(rowptr[-1]) and np.array_equal(np.diff(colptr), deg_i.cpu().numpy().astype(np.int64))
+    for i in (0, 1, m // 2, m - 1):
+        seg = users[colptr[i]:colptr[i + 1]].astype(np.int64)
+        assert np.all(np.diff(seg) > 0)
     D.close()

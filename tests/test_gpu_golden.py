@@ -1,0 +1,159 @@
+"""-m gpu: the reference's OWN vectors fed straight through the HIP phi passes.
+
+tests/golden/softmax.json and accumulate.json were produced by the reference's
+code compiled in place (D1Array::logsum / lognormalize / scale,
+matrix.hh:367-406; D2Array::add_slice, matrix.hh:1060-1067 -- see
+tests/golden/make_golden.py).  Here every case becomes a tiny ratings matrix
+with one nonzero per record whose Elog rows reproduce the record's x, the phi
+passes run on the GPU through the C-ABI, and the shape sums they produce are
+compared with the reference's phi / M directly -- no oracle in between
+(hgaprec.cc:206-239 get_phi, 1340-1366 the scatter of phi).
+
+Tolerance: the HIP path forms phi_k = y * W_k / sum_j W_j with
+W = exp(x - max x); the reference forms y * exp(x_k - logsum(x)) with a
+sequential log-add-exp whose own rounding grows with |x| (an ulp of logsum at
+|x| ~ 100 is 1.4e-14).  Measured against these vectors in numpy the two forms
+differ by <= 1.8e-14 relative (<= 5e-15 for spreads below 30), so the bound is
+4e-14 relative (+1e-300 absolute for the entries the reference leaves
+subnormal).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).parent / "golden"
+RTOL, ATOL = 4e-14, 1e-300
+
+
+def unhex(lst):
+    return np.array([float.fromhex(s) for s in lst], dtype=np.float64)
+
+
+def _close(got, want):
+    return np.all(np.abs(got - want) <= RTOL * np.abs(want) + ATOL)
+
+
+def _flat_model(n, m, K, bias):
+    from hgaprec_amd.capi import Hpf
+    D = Hpf(n, m, K, hier=False, bias=bias)
+    D.set_state("BETA_E", np.ones((m, K)))
+    return D
+
+
+def _cases_by_width():
+    d = json.loads((GOLD / "softmax.json").read_text())
+    by = {}
+    for c in d["cases"]:
+        by.setdefault(len(c["x"]), []).append(c)
+    return sorted(by.items())
+
+
+@pytest.mark.parametrize("width,cases", _cases_by_width(), ids=lambda v: str(v) if isinstance(v, int) else "")
+def test_softmax_golden_through_phi_passes(width, cases):
+    """record r -> user r, item r, one nonzero (r, r, y_r); Elog theta_r = x_r,
+    Elog beta_r = 0, so x_k = Elog theta + Elog beta is the record's x.  The
+    user-major pass must leave y*softmax(x) in theta's shape sums and the
+    item-major pass the same numbers in beta's."""
+    n = len(cases)
+    K = width
+    X = np.stack([unhex(c["x"]) for c in cases])
+    want = np.stack([unhex(c["phi"]) for c in cases])
+    y = np.array([c["y"] for c in cases], dtype=np.uint8)
+    rowptr = np.arange(n + 1, dtype=np.int64)
+    col = np.arange(n, dtype=np.uint32)
+
+    D = _flat_model(n, n, K, False)
+    D.upload_csr(rowptr, col, y)
+    D.set_state("THETA_ELOG", X)
+    D.set_state("BETA_ELOG", np.zeros((n, K)))
+    D.iterate_local_phi()
+    D.synchronize()
+    ld = (K + 1) & ~1
+    raw_items = D.exchange_read()[: n * ld].reshape(n, ld)[:, :K]      # item phi sums, no prior
+    assert _close(raw_items, want), np.max(np.abs(raw_items - want) / np.maximum(np.abs(want), 1e-300))
+    D.iterate_local_sweep()
+    D.iterate_global()
+    got = D.get_state("THETA_SHAPE")                                    # prior + user phi sums
+    assert np.all(np.abs(got - (0.3 + want)) <= 4e-16 + RTOL * want)
+    D.close()
+
+    # and with the roles swapped: x on the item side
+    D = _flat_model(n, n, K, False)
+    D.upload_csr(rowptr, col, y)
+    D.set_state("THETA_ELOG", np.zeros((n, K)))
+    D.set_state("BETA_ELOG", X)
+    D.iterate_local_phi()
+    D.synchronize()
+    raw_items = D.exchange_read()[: n * ld].reshape(n, ld)[:, :K]
+    assert _close(raw_items, want)
+    D.close()
+
+
+def _accumulate_cases():
+    return json.loads((GOLD / "accumulate.json").read_text())["cases"]
+
+
+@pytest.mark.parametrize("ci", range(3))
+@pytest.mark.parametrize("owner", ["user", "item"])
+def test_accumulate_golden_through_phi_passes(ci, owner):
+    """M = 0.3 + sum over records of the first K entries of y*softmax(x)
+    (add_slice adds only K of a K+2 wide phi, matrix.hh:1060-1067).  The owner
+    row of a record is a user (or an item); each record is a nonzero to its own
+    other-side row, whose Elog row carries the record's x.  With -bias the two
+    extra slots are the user-bias and item-bias Elog; the softmax is invariant
+    to a common shift, so x is shifted by the slot that belongs to the OWNER
+    (kept at Elog 0) -- one extra rounding of ~1 ulp(|x|) per entry."""
+    c = _accumulate_cases()[ci]
+    rows, K, width = c["rows"], c["K"], c["width"]
+    bias = width == K + 2
+    recs = c["recs"]
+    nrec = len(recs)
+    M = unhex(c["M"]).reshape(rows, K)
+    X = np.stack([unhex(r["x"]) for r in recs])
+    yv = np.array([r["y"] for r in recs], dtype=np.uint8)
+    own = np.array([r["row"] for r in recs])
+
+    if bias:
+        own_slot = K if owner == "user" else K + 1       # slot that belongs to the owner's side
+        oth_slot = K + 1 if owner == "user" else K
+        Xs = X - X[:, own_slot:own_slot + 1]
+        oth_main, oth_bias = Xs[:, :K], Xs[:, oth_slot]
+    else:
+        oth_main, oth_bias = X, None
+
+    if owner == "user":
+        n, m = rows, nrec
+        order = np.argsort(own, kind="stable")            # CSR: records grouped by owner user, file order kept
+        rowptr = np.zeros(n + 1, np.int64)
+        rowptr[1:] = np.cumsum(np.bincount(own, minlength=n))
+        col = order.astype(np.uint32)                     # record r <-> item r
+        val = yv[order]
+        D = _flat_model(n, m, K, bias)
+        D.upload_csr(rowptr, col, val)
+        D.set_state("THETA_ELOG", np.zeros((n, K)))
+        D.set_state("BETA_ELOG", oth_main)
+        if bias:
+            D.set_state("UBIAS_ELOG", np.zeros(n)); D.set_state("IBIAS_ELOG", oth_bias)
+            D.set_state("UBIAS_E", np.ones(n)); D.set_state("IBIAS_E", np.ones(m))
+        D.iterate(1)
+        got = D.get_state("THETA_SHAPE")
+    else:
+        n, m = nrec, rows
+        rowptr = np.arange(n + 1, dtype=np.int64)         # record r <-> user r, one nonzero each
+        col = own.astype(np.uint32)
+        D = _flat_model(n, m, K, bias)
+        D.upload_csr(rowptr, col, yv)
+        D.set_state("THETA_ELOG", oth_main)
+        D.set_state("BETA_ELOG", np.zeros((m, K)))
+        if bias:
+            D.set_state("UBIAS_ELOG", oth_bias); D.set_state("IBIAS_ELOG", np.zeros(m))
+            D.set_state("UBIAS_E", np.ones(n)); D.set_state("IBIAS_E", np.ones(m))
+        D.iterate(1)
+        got = D.get_state("BETA_SHAPE")
+    D.close()
+    err = np.max(np.abs(got - M) / np.abs(M))
+    assert err <= RTOL, err

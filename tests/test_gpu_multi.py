@@ -1,0 +1,258 @@
+"""-m gpu: the N > 1 paths with the REAL engine.
+
+ * world 2 over gloo, both ranks on GPU 0: hgaprec_amd/dist.py's protocol
+   (partition by nnz, one sum-all-reduce of the exchange buffer between
+   hpf_iterate_local and hpf_iterate_global) driving libhpf_hip.so -- runs on
+   the 1-GPU box (tests/test_dist_gloo.py keeps a numpy double of the engine
+   for the CPU-only suite).
+ * with >= 2 GPUs visible (the driver's multi-GPU node): RCCL across real
+   devices -- `hgaprec -ngpus 2 -comm rccl` against `-comm host`, the library's
+   own hpf_comm_init + hpf_iterate(h, n) on two devices, and `bench.py --gpus 2`.
+   Skipped on a 1-GPU box: ncclCommInitRank refuses two ranks on one device.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import compare_states, init_states, make_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+EXE = ROOT / "hgaprec_amd" / "hgaprec"
+
+N, M, K, NNZ, SEED, ITERS = 500, 300, 20, 12000, 13, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _problem(bias):
+    from oracle import orc
+    rowptr, col, val = make_problem(N, M, NNZ, SEED, heavy_item=True)
+    Mo = orc.Model(N, M, K, True, bias, False)
+    Mo.set_csr(rowptr, col, val)
+    Mo.initialize(5)
+    init = {w: Mo.state(w) for w in init_states(True, bias)}
+    Mo.iterate(ITERS)
+    final = {w: Mo.state(w) for w in compare_states(True, bias)}
+    return (rowptr, col, val), init, final
+
+
+def _check(D, final, a, b, bias):
+    errs = {}
+    for w in compare_states(True, bias):
+        want = final[w]
+        if w.startswith(("THETA_", "XI_", "UBIAS_")):       # user-side objects live on their owner rank
+            want = want[a:b]
+        errs[w] = rel_err(D.get_state(w), want)
+    return errs
+
+
+def _guard(fn):
+    """a failing rank reports instead of leaving the parent waiting on the queue"""
+    def run(rank, world, bias, port, q):
+        try:
+            fn(rank, world, bias, port, q)
+        except BaseException:
+            import traceback
+            q.put((rank, {"error": traceback.format_exc()}, {}))
+            raise
+    run.__name__ = fn.__name__
+    return run
+
+
+def _rank_gloo_body(rank, world, bias, port, q):
+    """one rank of the dist.py protocol: real engine on GPU 0, gloo all-reduce"""
+    import torch
+    import torch.distributed as dist
+    from hgaprec_amd import dist as hd
+    from hgaprec_amd.capi import Hpf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    (rowptr, col, val), init, final = _problem(bias)
+    a, b = hd.partition_users(rowptr, world)[rank]
+    rp, c, v = hd.shard_csr(rowptr, col, val, a, b)
+    D = Hpf(b - a, M, K, hier=True, bias=bias, device=0, n_ranks=world, rank=rank, n_users_total=N)
+    ex = hd.Exchange(D, device=torch.device("cuda", 0))
+    D.upload_csr(rp, c, v)
+    hd.scatter_state(D, init, a, b, hier=True)
+    for _ in range(ITERS):
+        D.iterate_local()
+        D.synchronize()
+        ex.allreduce()
+        torch.cuda.synchronize()
+        D.iterate_global()
+    q.put((rank, _check(D, final, a, b, bias), {}))
+    D.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rank_gloo(rank, world, bias, port, q):
+    _guard(_rank_gloo_body)(rank, world, bias, port, q)
+
+
+def _rank_rccl(rank, world, bias, port, q):
+    _guard(_rank_rccl_body)(rank, world, bias, port, q)
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_world2_gloo_real_engine(bias):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_gloo, args=(r, 2, bias, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in procs]
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for _, errs, _ in res:
+        assert "error" not in errs, errs["error"]
+        assert max(errs.values()) < 1e-9, errs
+
+
+def _rank_rccl_body(rank, world, bias, port, q):
+    """the library's own exchange: hpf_comm_init (dlopen'ed RCCL) + hpf_iterate(h, n),
+    one process per GPU; the 128-byte id travels over a gloo broadcast"""
+    import torch
+    import torch.distributed as dist
+    from hgaprec_amd import dist as hd
+    from hgaprec_amd.capi import Hpf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    (rowptr, col, val), init, final = _problem(bias)
+    a, b = hd.partition_users(rowptr, world)[rank]
+    rp, c, v = hd.shard_csr(rowptr, col, val, a, b)
+    D = Hpf(b - a, M, K, hier=True, bias=bias, device=rank, n_ranks=world, rank=rank, n_users_total=N)
+    D.upload_csr(rp, c, v)
+    hd.scatter_state(D, init, a, b, hier=True)
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        idt = torch.frombuffer(bytearray(Hpf.comm_unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(idt, 0)
+    D.comm_init(bytes(idt.numpy().tobytes()))
+    D.iterate(ITERS)                       # overlapped: items pass, all-reduce on a second stream, user half
+    D.synchronize()
+    errs = _check(D, final, a, b, bias)
+    t = D.last_timing()
+    q.put((rank, errs, t))
+    D.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_two_gpus_library_rccl_iterate(bias):
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_rccl, args=(r, 2, bias, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in procs]
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for _, errs, t in res:
+        assert "error" not in errs, errs["error"]
+        assert max(errs.values()) < 1e-9, errs
+        assert t["phi_item_ms"] > 0 and t["sweep_item_ms"] > 0 and t["exchange_wait_ms"] >= 0
+
+
+def test_two_gpus_cli_rccl_equals_host_staged(tmp_path):
+    """`hgaprec -ngpus 2 -comm rccl` (one process per GPU, RCCL all-reduce on a
+    second stream) writes the same files as `-comm host` (all-reduce staged
+    through the host star), which test_gpu_cli.py pins to the oracle"""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    from tests.test_gpu_cli import write_dataset
+    n, m, k = 300, 200, 6
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    base = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(k), "-seed", "7", "-rfreq", "2",
+            "-hier", "-bias", "-logl", "-max-iterations", "10", "-ngpus", "2"]
+    outs = {}
+    for comm in ("host", "rccl"):
+        wd = tmp_path / comm
+        wd.mkdir()
+        r = subprocess.run([str(EXE)] + base + ["-comm", comm], cwd=wd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (comm, r.stdout[-1500:], r.stderr[-1500:])
+        (out,) = [p for p in wd.iterdir() if p.is_dir()]
+        outs[comm] = out
+    skip = {"infer.log", "param.txt"}
+    names = sorted(p.name for p in outs["host"].iterdir() if p.name not in skip)
+    assert names == sorted(p.name for p in outs["rccl"].iterdir() if p.name not in skip)
+    for nm in names:
+        a, b = (outs["host"] / nm).read_text(), (outs["rccl"] / nm).read_text()
+        if nm in ("validation.txt", "test.txt", "max.txt", "logl.txt"):
+            # the seconds column differs; host-staged and RCCL sums may round differently
+            ca = [[x for k2, x in enumerate(l.split("\t")) if k2 != 1] for l in a.splitlines()]
+            cb = [[x for k2, x in enumerate(l.split("\t")) if k2 != 1] for l in b.splitlines()]
+            assert len(ca) == len(cb), nm
+            for ra, rb in zip(ca, cb):
+                assert len(ra) == len(rb)
+                for xa, xb in zip(ra, rb):
+                    assert abs(float(xa) - float(xb)) <= 1e-6 * max(1.0, abs(float(xb))), nm
+        elif nm.endswith(".tsv") and nm not in ("ranking.tsv", "itemrank.tsv", "byusers.tsv", "byitems.tsv"):
+            va = np.array([[float(x) for x in l.split("\t")[2:]] for l in a.splitlines()])
+            vb = np.array([[float(x) for x in l.split("\t")[2:]] for l in b.splitlines()])
+            assert va.shape == vb.shape and np.max(np.abs(va - vb)) <= 2.1e-8, nm
+        else:
+            assert a == b, nm
+
+
+def test_two_gpus_bench_strong_scaling_line():
+    """bench.py --gpus 2: C3 cut to 1 % (--scale), user-sharded, RCCL all-reduce
+    overlapped with the user half; the JSON line carries the strong-scaling fields"""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "0.01"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["replica_check"] == "ok"
+    assert d["self_check"]["ok"] and d["config"]["workload"].startswith("C3")
+    assert len(d["per_rank"]) == 2
+    nn = [r_["nnz"] for r_ in d["per_rank"]]
+    assert sum(nn) == d["config"]["nnz_total"] and abs(nn[0] - nn[1]) < 0.05 * sum(nn)
+
+
+def test_one_gpu_bench_takes_the_distributed_path():
+    """the N > 1 code path of bench.py (process group, bound exchange tensor, the
+    overlapped all-reduces) on one rank -- HPF_BENCH_FORCE_DIST=1 -- at 1 % of C2"""
+    env = dict(os.environ, HPF_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.01",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["replica_check"] == "ok" and d["self_check"]["ok"]
+    assert d["roofline"]["traffic"] is None and "per_rank" in d
