@@ -409,6 +409,17 @@ int Ratings::load_cache(const std::string &dir)
   bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, kCacheMagic, 8) && fingerprint(dir, &want);
   ok = ok && h.cap_n == cap_n && h.cap_m == cap_m && h.binary == (uint32_t)binary && h.rating_threshold == rating_threshold;
   for (int j = 0; ok && j < 3; ++j) ok = h.src_size[j] == want.src_size[j] && h.src_mtime_ns[j] == want.src_mtime_ns[j];
+  // the counts must account for the file's size exactly BEFORE anything is allocated from
+  // them (a damaged header must not turn into a multi-terabyte resize), and they must fit
+  // the capacities this run was started with
+  if (ok) {
+    struct stat st;
+    ok = fstat(fileno(f), &st) == 0 && h.n <= cap_n && h.m <= cap_m;
+    const long double want_bytes = (long double)sizeof h + 4.0L * h.n + 4.0L * h.m + 8.0L * ((long double)h.n + 1) +
+                                   5.0L * (long double)h.nnz + 12.0L * (long double)h.n_validation +
+                                   12.0L * (long double)h.n_test + 8.0L;
+    ok = ok && want_bytes == (long double)st.st_size;
+  }
   Ratings t;                                    // only committed when the whole image checks out
   ok = ok && get_vec(f, &t.seq2user, h.n) && get_vec(f, &t.seq2item, h.m) && get_vec(f, &t.rowptr, (size_t)h.n + 1);
   ok = ok && get_vec(f, &t.col, h.nnz) && get_vec(f, &t.val, h.nnz);
@@ -418,6 +429,11 @@ int Ratings::load_cache(const std::string &dir)
   ok = ok && fread(&tail, 8, 1, f) == 1 && tail == kCacheTail;
   fclose(f);
   ok = ok && t.rowptr.front() == 0 && (uint64_t)t.rowptr.back() == h.nnz;
+  // every index the rest of the program will use as a subscript
+  for (uint32_t u = 0; ok && u < h.n; ++u) ok = t.rowptr[u] <= t.rowptr[u + 1];
+  for (size_t j = 0; ok && j < t.col.size(); ++j) ok = t.col[j] < h.m;
+  for (const HeldOut *ho : {&t.validation, &t.test})
+    for (size_t j = 0; ok && j < ho->u.size(); ++j) ok = ho->u[j] < h.n && ho->i[j] < h.m;
   if (!ok) return 1;
   n = h.n; m = h.m; nratings = h.nnz;
   seq2user.swap(t.seq2user); seq2item.swap(t.seq2item); rowptr.swap(t.rowptr); col.swap(t.col); val.swap(t.val);
@@ -792,6 +808,7 @@ bool StopRule::update(uint32_t iter, double a, int *why)
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 
 namespace hgaprec {
@@ -811,29 +828,48 @@ int recv_all(int fd, void *p, size_t n)
 }
 }  // namespace
 
+// Rank 0 listens on `addr` only (MASTER_ADDR, default 127.0.0.1: the feature is
+// one process per GPU of ONE node), the handshake carries the rank and a
+// 64-bit nonce that the launcher (spawn_ranks) hands to its children through
+// HGAPREC_NONCE, and both the accept loop and the handshake reads time out.
 int Comm::init(int rank_, int world_, const std::string &addr, int port)
 {
   rank = rank_; world = world_;
   if (world <= 1) return 0;
+  uint64_t nonce = 0;
+  if (const char *e = getenv("HGAPREC_NONCE")) nonce = strtoull(e, nullptr, 16);
+  struct Hello { int32_t rank; uint32_t magic; uint64_t nonce; };
+  const uint32_t magic = 0x48504631u;                      // "HPF1"
+  sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+  if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) return -1;
   if (rank == 0) {
     int ls = ::socket(AF_INET, SOCK_STREAM, 0);
     if (ls < 0) return -1;
     int one = 1; setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-    sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
     if (::bind(ls, (sockaddr *)&sa, sizeof sa) < 0 || ::listen(ls, world) < 0) { ::close(ls); return -1; }
     fds.assign(world, -1);
-    for (int k = 1; k < world; ++k) {
+    int have = 1, strangers = 0;
+    while (have < world) {
+      pollfd pf{ls, POLLIN, 0};
+      const int pr = ::poll(&pf, 1, 120000);               // a rank that never shows up must not hang the job
+      if (pr < 0 && errno == EINTR) continue;
+      if (pr <= 0) { ::close(ls); close_all(); return -1; }
       int fd = ::accept(ls, nullptr, nullptr);
-      if (fd < 0) { ::close(ls); return -1; }
+      if (fd < 0) { if (errno == EINTR) continue; ::close(ls); close_all(); return -1; }
+      timeval tv{10, 0}; setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+      Hello hl{-1, 0, 0};
+      if (recv_all(fd, &hl, sizeof hl) || hl.magic != magic || hl.nonce != nonce || hl.rank <= 0 ||
+          hl.rank >= world || fds[hl.rank] >= 0) {
+        ::close(fd);                                       // not one of ours: drop it, keep listening
+        if (++strangers > 64) { ::close(ls); close_all(); return -1; }
+        continue;
+      }
+      timeval off{0, 0}; setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &off, sizeof off);
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-      int32_t r = -1;
-      if (recv_all(fd, &r, 4) || r <= 0 || r >= world || fds[r] >= 0) { ::close(fd); ::close(ls); return -1; }
-      fds[r] = fd;
+      fds[hl.rank] = fd; ++have;
     }
     ::close(ls);
   } else {
-    sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
-    if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) return -1;
     int fd = -1;
     for (int tries = 0; tries < 600; ++tries) {            // rank 0 may not listen yet
       fd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -844,8 +880,8 @@ int Comm::init(int rank_, int world_, const std::string &addr, int port)
     }
     if (fd < 0) return -1;
     int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    int32_t r = rank;
-    if (send_all(fd, &r, 4)) { ::close(fd); return -1; }
+    Hello hl{rank, magic, nonce};
+    if (send_all(fd, &hl, sizeof hl)) { ::close(fd); return -1; }
     fds.assign(1, fd);
   }
   return 0;

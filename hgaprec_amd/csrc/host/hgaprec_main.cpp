@@ -59,6 +59,20 @@ struct Driver {
     fprintf(stderr, "error: [rank %d] %s: %s (%s)\n", comm.rank, what, hpf_strerror(rc), h ? hpf_last_error(h) : "");
     exit(-1);
   }
+  // output failures are fatal and say which file: a truncated factor file or a
+  // missing part must never end in exit code 0
+  [[noreturn]] void io_die(const char *what, const std::string &path) {
+    fprintf(stderr, "error: [rank %d] %s %s: %s\n", comm.rank, what, path.c_str(), strerror(errno));
+    exit(-1);
+  }
+  FILE *open_or_die(const std::string &path, const char *mode) {
+    FILE *f = fopen(path.c_str(), mode);
+    if (!f) io_die("cannot open", path);
+    return f;
+  }
+  void close_or_die(FILE *f, const std::string &path) {
+    if (ferror(f) | fclose(f)) io_die("cannot write", path);
+  }
   void comm_check(int rc, const char *what) {
     if (rc) { fprintf(stderr, "error: [rank %d] %s: peer lost\n", comm.rank, what); exit(-1); }
   }
@@ -195,17 +209,20 @@ struct Driver {
     if (comm.world == 1) return;
     comm_check(comm.barrier(), "barrier");
     if (root()) {
-      FILE *out = fopen(path.c_str(), "w");
+      FILE *out = open_or_die(path, "w");
       std::vector<char> buf(1 << 20);
       for (int r = 0; r < comm.world; ++r) {
-        FILE *in = fopen(part_name(path, r).c_str(), "r");
-        if (!in) continue;
+        const std::string pn = part_name(path, r);
+        FILE *in = fopen(pn.c_str(), "r");
+        if (!in) io_die("missing part file", pn);           // every rank writes one, even if empty
         size_t got;
-        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0) fwrite(buf.data(), 1, got, out);
+        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0)
+          if (fwrite(buf.data(), 1, got, out) != got) io_die("cannot write", path);
+        if (ferror(in)) io_die("cannot read", pn);
         fclose(in);
-        unlink(part_name(path, r).c_str());
+        unlink(pn.c_str());
       }
-      fclose(out);
+      close_or_die(out, path);
     }
     comm_check(comm.barrier(), "barrier");
   }
@@ -228,12 +245,16 @@ struct Driver {
       const std::string path = base + suf[j];
       const bool vec = j == 1 && vec_rate;       // GPMatrixGR rate: K-vector, ids looked up by k
       if (vec) {
-        if (root()) { get((hpf_state)(shape + 1), cols); save_vector(path, buf.data(), cols, ids.data(), (uint32_t)ids.size()); }
+        if (root()) {
+          get((hpf_state)(shape + 1), cols);
+          if (save_vector(path, buf.data(), cols, ids.data(), (uint32_t)ids.size())) io_die("cannot write", path);
+        }
         continue;
       }
       if (mine) {
         get((hpf_state)(shape + j), (size_t)rows * cols);
-        save_matrix(user_side ? my_path(path) : path, buf.data(), rows, cols, ids.data(), (uint32_t)ids.size(), row0);
+        const std::string dst = user_side ? my_path(path) : path;
+        if (save_matrix(dst, buf.data(), rows, cols, ids.data(), (uint32_t)ids.size(), row0)) io_die("cannot write", dst);
       }
       if (user_side) finish_parts(path);
     }
@@ -249,7 +270,8 @@ struct Driver {
       if (user_side || root()) {
         int rc = hpf_get_state(h, (hpf_state)(shape + j), buf.data(), rows);
         if (rc) die("hpf_get_state", rc);
-        save_vector(user_side ? my_path(path) : path, buf.data(), rows, ids.data(), (uint32_t)ids.size(), row0);
+        const std::string dst = user_side ? my_path(path) : path;
+        if (save_vector(dst, buf.data(), rows, ids.data(), (uint32_t)ids.size(), row0)) io_die("cannot write", dst);
       }
       if (user_side) finish_parts(path);
     }
@@ -302,7 +324,7 @@ struct Driver {
   void compute_precision(bool save_ranking_file) {          // hgaprec.cc:1703-1848
     if (iter % 100 == 0 && iter > 0) save_ranking_file = true;
     const std::string rpath = env.file_str("/ranking.tsv");
-    FILE *f = save_ranking_file ? fopen(my_path(rpath).c_str(), "w") : nullptr;
+    FILE *f = save_ranking_file ? open_or_die(my_path(rpath), "w") : nullptr;
     if (!save_ranking_file) {                    // hgaprec.cc:1714-1721 (same draws on every rank)
       sampled.clear();
       do {
@@ -335,7 +357,7 @@ struct Driver {
       }
       acc[0] += (double)hits10 / 10; acc[1] += (double)hits100 / 100; acc[2] += 1;
     }
-    if (f) fclose(f);
+    if (f) close_or_die(f, my_path(rpath));
     if (save_ranking_file) finish_parts(rpath);
     comm_check(comm.allreduce_sum(acc, 3), "precision all-reduce");
     if (root()) {
@@ -349,7 +371,7 @@ struct Driver {
     if (iter % 100 == 0 && iter > 0) final = true;
     if (!final) return;
     const std::string ipath = env.file_str("/itemrank.tsv");
-    FILE *f = fopen(my_path(ipath).c_str(), "w");
+    FILE *f = open_or_die(my_path(ipath), "w");
     if (item_deg.empty()) { item_deg.assign(m, 0); for (uint32_t c : rt.col) item_deg[c]++; }
     std::vector<uint32_t> lus; std::vector<uint64_t> mptr; std::vector<uint32_t> mitems;
     local_sample(lus, mptr, mitems);
@@ -391,7 +413,7 @@ struct Driver {
       }
       q0 = q1;
     }
-    fclose(f);
+    close_or_die(f, my_path(ipath));
     finish_parts(ipath);
     comm_check(comm.allreduce_sum(acc, 3), "itemrank all-reduce");
     if (root()) {
@@ -435,9 +457,9 @@ struct Driver {
     int why = -1;
     const bool st = stop.update(iter, a, &why);   // same value on every rank => same decision
     if (root()) {
-      FILE *f = fopen(env.file_str("/max.txt").c_str(), "w");
+      FILE *f = open_or_die(env.file_str("/max.txt"), "w");
       fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, duration(), a, why);
-      fclose(f);
+      close_or_die(f, env.file_str("/max.txt"));
     }
     if (st) { do_on_stop(); return true; }
     return false;
@@ -471,24 +493,26 @@ struct Driver {
   }
   void write_checkpoint() {
     const std::string path = checkpoint_path(), tmp = path + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) { fprintf(stderr, "warning: cannot write %s\n", tmp.c_str()); return; }
+    FILE *f = open_or_die(tmp, "wb");
+    bool ok = true;
+    auto put = [&](const void *p, size_t sz, size_t cnt) { ok = ok && fwrite(p, sz, cnt, f) == cnt; };
     const uint32_t head[13] = {1u, (uint32_t)comm.world, (uint32_t)comm.rank, n, lo, hi, m, k,
                                (uint32_t)env.hier, (uint32_t)env.bias, (uint32_t)env.binary_data, iter + 1, stop.nh};
-    fwrite("HPFCKPT1", 1, 8, f); fwrite(head, 4, 13, f); fwrite(&stop.prev_h, 8, 1, f);
-    fwrite(rng.mt, 4, 624, f); const int32_t mti = rng.mti; fwrite(&mti, 4, 1, f);
-    const uint32_t ns = (uint32_t)sampled.size(); fwrite(&ns, 4, 1, f); fwrite(sampled.data(), 4, ns, f);
+    put("HPFCKPT1", 1, 8); put(head, 4, 13); put(&stop.prev_h, 8, 1);
+    put(rng.mt, 4, 624); const int32_t mti = rng.mti; put(&mti, 4, 1);
+    const uint32_t ns = (uint32_t)sampled.size(); put(&ns, 4, 1); put(sampled.data(), 4, ns);
     std::vector<double> buf;
     for (hpf_state w : checkpoint_states()) {
       const uint64_t cnt = state_count(w); const uint32_t id = (uint32_t)w;
       buf.resize(cnt);
       int rc = hpf_get_state(h, w, buf.data(), cnt);
       if (rc) die("hpf_get_state (checkpoint)", rc);
-      fwrite(&id, 4, 1, f); fwrite(&cnt, 8, 1, f); fwrite(buf.data(), 8, cnt, f);
+      put(&id, 4, 1); put(&cnt, 8, 1); put(buf.data(), 8, cnt);
     }
-    const uint32_t end = 0xffffffffu; fwrite(&end, 4, 1, f);
-    fclose(f);
-    rename(tmp.c_str(), path.c_str());
+    const uint32_t end = 0xffffffffu; put(&end, 4, 1);
+    // a checkpoint that did not reach the disk must not replace the previous good one
+    if (!ok || (ferror(f) | fclose(f))) { unlink(tmp.c_str()); io_die("cannot write", tmp); }
+    if (rename(tmp.c_str(), path.c_str())) io_die("cannot rename checkpoint to", path);
   }
   void read_checkpoint() {
     const std::string path = checkpoint_path();
@@ -558,6 +582,13 @@ int spawn_ranks(int ngpus, char **argv)
 {
   int port = 20000 + (int)(getpid() % 20000);
   if (const char *e = getenv("MASTER_PORT")) port = atoi(e);
+  // the children prove they are ours with a random nonce (Comm::init)
+  {
+    unsigned long long nonce = (unsigned long long)getpid() * 0x9E3779B97F4A7C15ull ^ (unsigned long long)time(nullptr);
+    if (FILE *f = fopen("/dev/urandom", "rb")) { if (fread(&nonce, 8, 1, f) != 1) {} fclose(f); }
+    char buf[32]; snprintf(buf, sizeof buf, "%llx", nonce);
+    setenv("HGAPREC_NONCE", buf, 1);
+  }
   std::vector<pid_t> kids;
   for (int r = 0; r < ngpus; ++r) {
     pid_t pid = fork();
@@ -611,6 +642,11 @@ int main(int argc, char **argv)
     fflush(stdout);
     abort();                                    // the reference asserts (main.cc:227-230)
   }
+  // -novb only changes the reference's behaviour in vb_bias() (-bias without -hier): there the
+  // rates of BOTH sides are built from the previous iteration's expectations before anything is
+  // swapped (hgaprec.cc:1276-1297, a Jacobi order); vb() and vb_hier() never read the flag.
+  // That ordering is not built here: refuse it instead of silently fitting the default order.
+  if (!env.vb && env.bias && !env.hier && env.unsupported.empty()) env.unsupported = "-novb (with -bias, without -hier)";
   if (!env.unsupported.empty()) {
     fprintf(stderr, "error: option %s selects a mode outside the MI355X hot-path build "
                     "(supported: -dir -n -m -k -hier -bias -binary-data -rfreq -max-iterations "

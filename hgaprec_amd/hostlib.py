@@ -5,12 +5,15 @@ callers that want the reference's file semantics without the CLI."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libhgaprec_host.so"
+# HGAPREC_HOST_LIB: load another build of the same library (the ASan/UBSan one,
+# tests/test_host_sanitizers.py)
+LIB_PATH = Path(os.environ.get("HGAPREC_HOST_LIB") or _PKG / "libhgaprec_host.so")
 _lib = None
 
 
