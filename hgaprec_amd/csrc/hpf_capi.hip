@@ -1032,6 +1032,12 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (cfg->w_storage > 1) { delete h; return HPF_ERR_INVALID; }
   // 16-byte rows of W: 2 doubles or 4 floats
   h->K = cfg->K; h->C = C; h->ld = h->w32 ? (C + 3u) & ~3u : (C + 1u) & ~1u;
+  // HPF_LD_ROUND=r (experiments): round the row stride up to a multiple of r doubles, e.g. 16
+  // makes every row start on a 128-byte line (K=100: 800-byte rows become 896)
+  if (const char *e = getenv("HPF_LD_ROUND")) {
+    const int r = atoi(e);
+    if (r >= 2 && r <= 64 && (r & (r - 1)) == 0 && (!h->w32 || r >= 4)) h->ld = (h->ld + (uint32_t)r - 1) & ~((uint32_t)r - 1);
+  }
 
   auto fail = [&](int rc) { hpf_destroy(h); return rc; };
   if (cfg->stream) h->stream = (hipStream_t)cfg->stream;

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Profiling recipe of a round, run ON the GPU box from the repo root:
+#   bash tools/profile_round.sh r02
+# Writes under gpurun_out/<tag>/ ; tools/summarize_profiles.py turns that into profiles/<tag>/.
+# Counters are collected in their own passes (--kernel-trace --pmc only), as the
+# MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass.
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+# 1. per-kernel time, same command as the bench line next to it
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o c2 -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.log
+# 2. counters, one pass each
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $pmc | tr ' ' '_' | tr 'A-Z' 'a-z')
+  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$name -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$name.log
+done
+# 3. the plain bench line (with the CPU baseline)
+python bench.py --host-handover > $OUT/bench.json 2> $OUT/bench.log
+# 4. XCD-locality probe: times, then L2 hit rate and fabric bytes of base vs xcd
+for v in base xcd m2000; do python tools/xcd_locality_probe.py $v 10 > $OUT/xcd_$v.json 2> $OUT/xcd_$v.log; done
+for v in base xcd; do
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/xcd_pmc_tcc_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_tcc_$v.log
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/xcd_pmc_fetch_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_fetch_$v.log
+done
+# 5. row stride rounded to a 128-byte line (K=100: 800 -> 896 bytes)
+HPF_LD_ROUND=16 $BENCH > $OUT/bench_ld16.json 2> $OUT/bench_ld16.log
+# 6. the other configs on one GPU
+python bench.py --config C4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.log
+python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --host-handover > $OUT/bench_c3_full_1gpu.json 2> $OUT/bench_c3_full_1gpu.log
+python bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_full_1gpu.json 2> $OUT/bench_c5_full_1gpu.log
+ls -la $OUT

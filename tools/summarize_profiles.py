@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""gpurun_out/<tag>/ (raw rocprofv3 output of tools/profile_round.sh) ->
+profiles/<tag>/ (the summaries that are committed) + profiles/traffic.json.
+
+  python tools/summarize_profiles.py r02
+"""
+import csv
+import glob
+import hashlib
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def kernels_sha():
+    h = hashlib.sha256()
+    for f in ("hpf_kernels.hpp", "hpf_capi.hip"):
+        h.update((ROOT / "hgaprec_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("hpf::", "")
+    return name.split("(")[0]
+
+
+def counter_means(d):
+    """{kernel: {counter: (mean value per dispatch, dispatches)}} of one --pmc pass"""
+    out = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in out.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src, dst = ROOT / "gpurun_out" / tag, ROOT / "profiles" / tag
+    dst.mkdir(parents=True, exist_ok=True)
+    for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, dst / "kernel_stats.csv")
+    for f in glob.glob(str(src / "stats" / "**" / "*domain_stats.csv"), recursive=True):
+        shutil.copy(f, dst / "domain_stats.csv")
+    for f in src.glob("*.json"):
+        shutil.copy(f, dst / f.name)
+    ours = ("phi_pass_kernel", "row_sweep", "combine_partials", "colsum_finalize", "radix_", "item_hist", "scan_",
+            "derive_w", "repack_", "colsum_partial")
+    rows = []
+    traffic = {}
+    passes = {p.name: counter_means(p) for p in src.glob("pmc_*") if p.is_dir()}
+    merged = defaultdict(dict)
+    for cm in passes.values():
+        for k, cs in cm.items():
+            merged[k].update(cs)
+    for k in sorted(merged):
+        if not any(o in k for o in ours):
+            continue
+        cs = merged[k]
+        row = {"kernel": k, "dispatches": max(v[1] for v in cs.values())}
+        for c, (mean, _) in sorted(cs.items()):
+            row[c] = round(mean, 1)
+        if "TCC_HIT_sum" in cs and "TCC_MISS_sum" in cs:
+            h_, m_ = cs["TCC_HIT_sum"][0], cs["TCC_MISS_sum"][0]
+            row["L2_hit_rate"] = round(h_ / max(h_ + m_, 1.0), 4)
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            # KiB counters; FETCH_SIZE counts 64 B per 128-B request on gfx950 => x2 (MI355X_MICROARCH.md, HBM)
+            row["hbm_side_bytes"] = int((2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024)
+        rows.append(row)
+    if rows:
+        keys = sorted({k for r in rows for k in r}, key=lambda k: (k != "kernel", k))
+        with open(dst / "pmc_summary.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=keys)
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            if "hbm_side_bytes" in r and "phi_pass_kernel" in r["kernel"]:
+                side = "phi_item" if r["kernel"].rstrip(">").endswith("1") else "phi_user"
+                traffic[f"C2:{side}"] = r["hbm_side_bytes"]
+    # XCD probe
+    xcd = {}
+    for v in ("base", "xcd", "m2000"):
+        p = src / f"xcd_{v}.json"
+        if p.exists() and p.read_text().strip():
+            xcd[v] = json.loads(p.read_text().strip().splitlines()[-1])
+        for kind in ("tcc", "fetch"):
+            d = src / f"xcd_pmc_{kind}_{v}"
+            if d.is_dir():
+                cm = counter_means(d)
+                for k, cs in cm.items():
+                    if "phi_pass_kernel" in k:
+                        side = "item" if k.rstrip(">").endswith("1") else "user"
+                        xcd.setdefault(v, {}).setdefault("pmc_" + side, {}).update({c: round(x[0], 1) for c, x in cs.items()})
+    if xcd:
+        (dst / "xcd_locality_probe.json").write_text(json.dumps(xcd, indent=1))
+    if traffic:
+        traffic["kernels_sha"] = kernels_sha()
+        traffic["measured"] = f"profiles/{tag}/pmc_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, bench.py --steps 3 --warmup 1"
+        (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+    c3 = src / "bench_c3_full_1gpu.json"
+    if c3.exists() and c3.read_text().strip():
+        d = json.loads(c3.read_text().strip().splitlines()[-1])
+        (ROOT / "profiles" / "c3_1gpu_reference.json").write_text(json.dumps(
+            {"ms_per_step": d["ms_per_step"], "value": d["value"], "nnz_total": d["config"]["nnz_total"],
+             "kernels_ms": d["kernels_ms"], "measured": f"profiles/{tag}/bench_c3_full_1gpu.json"}, indent=1) + "\n")
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main()
