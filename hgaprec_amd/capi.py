@@ -37,6 +37,7 @@ EXPORTS = [
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
     "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_items_begin", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
     "hpf_algorithmic_bytes",
+    "hpf_snapshot_size", "hpf_snapshot_save", "hpf_snapshot_load",
     "hpf_get_work_info", "hpf_upload_csr_device", "hpf_get_csc", "hpf_set_state_device", "hpf_get_state_device",
 ]
 
@@ -100,6 +101,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_destroy.argtypes = [vp]
     lib.hpf_destroy.restype = None
     lib.hpf_upload_csr.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
+    lib.hpf_snapshot_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.hpf_snapshot_save.argtypes = [vp, vp, C.c_size_t]
+    lib.hpf_snapshot_load.argtypes = [vp, vp, C.c_size_t]
     lib.hpf_get_work_info.argtypes = [vp, C.POINTER(HpfWorkInfo)]
     lib.hpf_upload_csr_device.argtypes = [vp, vp, vp, vp]
     lib.hpf_get_csc.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
@@ -311,7 +315,19 @@ class Hpf:
         self._check(self.lib.hpf_exchange_write(self._h, _ptr(a, C.c_double), a.size))
 
     @staticmethod
+    def _rccl_of_this_process():
+        """The library dlopen()s librccl.so.1 on first use.  In a Python process that
+        also uses torch, torch's own copy (same SONAME, possibly another version) must
+        be the one that is mapped: whichever loads first is what BOTH get.  Importing
+        torch first makes that torch's -- one RCCL per process, deterministically."""
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+    @staticmethod
     def comm_unique_id() -> bytes:
+        Hpf._rccl_of_this_process()
         buf = C.create_string_buffer(128)
         rc = load_library().hpf_comm_unique_id(buf)
         if rc != HPF_OK:
@@ -319,6 +335,7 @@ class Hpf:
         return buf.raw
 
     def comm_init(self, unique_id: bytes):
+        self._rccl_of_this_process()
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.lib.hpf_comm_init(self._h, buf))
 
@@ -392,6 +409,18 @@ class Hpf:
         t = HpfTiming()
         self._check(self.lib.hpf_mean_timing(self._h, int(n_last), C.byref(t)))
         return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
+
+    def snapshot(self) -> np.ndarray:
+        """the loop's device state as one opaque blob (uint8 array)"""
+        n = C.c_size_t()
+        self._check(self.lib.hpf_snapshot_size(self._h, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        self._check(self.lib.hpf_snapshot_save(self._h, C.c_void_p(buf.ctypes.data), n.value))
+        return buf
+
+    def restore(self, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self.lib.hpf_snapshot_load(self._h, C.c_void_p(blob.ctypes.data), blob.size))
 
     def work_info(self) -> dict:
         w = HpfWorkInfo()

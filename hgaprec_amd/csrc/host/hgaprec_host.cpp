@@ -830,14 +830,13 @@ int recv_all(int fd, void *p, size_t n)
 
 // Rank 0 listens on `addr` only (MASTER_ADDR, default 127.0.0.1: the feature is
 // one process per GPU of ONE node), the handshake carries the rank and a
-// 64-bit nonce that the launcher (spawn_ranks) hands to its children through
-// HGAPREC_NONCE, and both the accept loop and the handshake reads time out.
-int Comm::init(int rank_, int world_, const std::string &addr, int port)
+// 64-bit nonce (the launcher, spawn_ranks, hands one to its children through
+// HGAPREC_NONCE; main() passes it in), and both the accept loop and the
+// handshake reads time out.
+int Comm::init(int rank_, int world_, const std::string &addr, int port, uint64_t nonce)
 {
   rank = rank_; world = world_;
   if (world <= 1) return 0;
-  uint64_t nonce = 0;
-  if (const char *e = getenv("HGAPREC_NONCE")) nonce = strtoull(e, nullptr, 16);
   struct Hello { int32_t rank; uint32_t magic; uint64_t nonce; };
   const uint32_t magic = 0x48504631u;                      // "HPF1"
   sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);

@@ -182,7 +182,9 @@ struct StopRule {
 struct Comm {
   int rank = 0, world = 1;
   std::vector<int> fds;       // rank 0: one socket per peer (index = peer rank); others: fds[0]
-  int init(int rank_, int world_, const std::string &addr, int port);   // 0 / -1
+  // nonce: shared secret of the job (0 when the launcher gave none); a peer that does not
+  // present it is dropped.  0 / -1
+  int init(int rank_, int world_, const std::string &addr, int port, uint64_t nonce = 0);
   void close_all();
   int allreduce_sum(double *v, size_t n);
   int allreduce_max(double *v, size_t n);

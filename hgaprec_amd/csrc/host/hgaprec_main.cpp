@@ -478,37 +478,25 @@ struct Driver {
   std::string checkpoint_path() const {
     return env.file_str("/checkpoint.r" + std::to_string(comm.rank) + "of" + std::to_string(comm.world) + ".bin");
   }
-  std::vector<hpf_state> checkpoint_states() const {
-    std::vector<hpf_state> v = {HPF_THETA_SHAPE, HPF_THETA_RATE, HPF_THETA_E, HPF_THETA_ELOG,
-                                HPF_BETA_SHAPE, HPF_BETA_RATE, HPF_BETA_E, HPF_BETA_ELOG};
-    if (env.hier) for (int w = HPF_XI_SHAPE; w <= HPF_ETA_ELOG; ++w) v.push_back((hpf_state)w);
-    if (env.bias) for (hpf_state w : {HPF_UBIAS_SHAPE, HPF_UBIAS_E, HPF_UBIAS_ELOG, HPF_IBIAS_SHAPE, HPF_IBIAS_E, HPF_IBIAS_ELOG}) v.push_back(w);
-    return v;
-  }
-  size_t state_count(hpf_state w) const {
-    const int obj = w / 4, kind = w % 4;
-    const size_t rows = (obj == 0 || obj == 2 || obj == 4) ? hi - lo : m;
-    if (obj <= 1) return (kind == 1 && !env.hier) ? k : rows * k;
-    return rows;
-  }
+  // -checkpoint N / -resume (extension).  The device part is hpf_snapshot_save's blob: the
+  // loop's arrays verbatim, so a resumed run continues with the bits of an uninterrupted one
+  // (same LL series, same stop iteration, same top-N ties).
   void write_checkpoint() {
     const std::string path = checkpoint_path(), tmp = path + ".tmp";
     FILE *f = open_or_die(tmp, "wb");
     bool ok = true;
     auto put = [&](const void *p, size_t sz, size_t cnt) { ok = ok && fwrite(p, sz, cnt, f) == cnt; };
-    const uint32_t head[13] = {1u, (uint32_t)comm.world, (uint32_t)comm.rank, n, lo, hi, m, k,
+    const uint32_t head[13] = {2u, (uint32_t)comm.world, (uint32_t)comm.rank, n, lo, hi, m, k,
                                (uint32_t)env.hier, (uint32_t)env.bias, (uint32_t)env.binary_data, iter + 1, stop.nh};
-    put("HPFCKPT1", 1, 8); put(head, 4, 13); put(&stop.prev_h, 8, 1);
+    put("HPFCKPT2", 1, 8); put(head, 4, 13); put(&stop.prev_h, 8, 1);
     put(rng.mt, 4, 624); const int32_t mti = rng.mti; put(&mti, 4, 1);
     const uint32_t ns = (uint32_t)sampled.size(); put(&ns, 4, 1); put(sampled.data(), 4, ns);
-    std::vector<double> buf;
-    for (hpf_state w : checkpoint_states()) {
-      const uint64_t cnt = state_count(w); const uint32_t id = (uint32_t)w;
-      buf.resize(cnt);
-      int rc = hpf_get_state(h, w, buf.data(), cnt);
-      if (rc) die("hpf_get_state (checkpoint)", rc);
-      put(&id, 4, 1); put(&cnt, 8, 1); put(buf.data(), 8, cnt);
-    }
+    size_t bytes = 0;
+    int rc = hpf_snapshot_size(h, &bytes);
+    if (rc) die("hpf_snapshot_size", rc);
+    std::vector<char> blob(bytes);
+    if ((rc = hpf_snapshot_save(h, blob.data(), bytes))) die("hpf_snapshot_save", rc);
+    const uint64_t b64 = bytes; put(&b64, 8, 1); put(blob.data(), 1, bytes);
     const uint32_t end = 0xffffffffu; put(&end, 4, 1);
     // a checkpoint that did not reach the disk must not replace the previous good one
     if (!ok || (ferror(f) | fclose(f))) { unlink(tmp.c_str()); io_die("cannot write", tmp); }
@@ -520,24 +508,24 @@ struct Driver {
     if (!f) { fprintf(stderr, "error: [rank %d] -resume: cannot open %s\n", comm.rank, path.c_str()); exit(-1); }
     auto need = [&](bool ok) { if (!ok) { fprintf(stderr, "error: [rank %d] %s is not a checkpoint of this run\n", comm.rank, path.c_str()); exit(-1); } };
     char magic[8]; uint32_t head[13];
-    need(fread(magic, 1, 8, f) == 8 && !memcmp(magic, "HPFCKPT1", 8) && fread(head, 4, 13, f) == 13);
-    need(head[0] == 1 && head[1] == (uint32_t)comm.world && head[2] == (uint32_t)comm.rank && head[3] == n &&
+    need(fread(magic, 1, 8, f) == 8 && !memcmp(magic, "HPFCKPT2", 8) && fread(head, 4, 13, f) == 13);
+    need(head[0] == 2 && head[1] == (uint32_t)comm.world && head[2] == (uint32_t)comm.rank && head[3] == n &&
          head[4] == lo && head[5] == hi && head[6] == m && head[7] == k && head[8] == (uint32_t)env.hier &&
          head[9] == (uint32_t)env.bias && head[10] == (uint32_t)env.binary_data);
     iter = head[11]; stop.nh = head[12];
     need(fread(&stop.prev_h, 8, 1, f) == 1 && fread(rng.mt, 4, 624, f) == 624);
-    int32_t mti; need(fread(&mti, 4, 1, f) == 1); rng.mti = mti;
-    uint32_t ns; need(fread(&ns, 4, 1, f) == 1); sampled.resize(ns); need(fread(sampled.data(), 4, ns, f) == ns);
-    std::vector<double> buf;
-    while (true) {
-      uint32_t id; need(fread(&id, 4, 1, f) == 1);
-      if (id == 0xffffffffu) break;
-      uint64_t cnt; need(fread(&cnt, 8, 1, f) == 1 && id < HPF_NUM_STATE && cnt == state_count((hpf_state)id));
-      buf.resize(cnt); need(fread(buf.data(), 8, cnt, f) == cnt);
-      int rc = hpf_set_state(h, (hpf_state)id, buf.data(), cnt);
-      if (rc) die("hpf_set_state (resume)", rc);
-    }
+    int32_t mti; need(fread(&mti, 4, 1, f) == 1 && mti >= 0 && mti <= 624); rng.mti = mti;
+    uint32_t ns; need(fread(&ns, 4, 1, f) == 1 && ns <= n); sampled.resize(ns); need(fread(sampled.data(), 4, ns, f) == ns);
+    size_t want = 0;
+    int rc = hpf_snapshot_size(h, &want);
+    if (rc) die("hpf_snapshot_size", rc);
+    uint64_t b64 = 0;
+    need(fread(&b64, 8, 1, f) == 1 && b64 >= 64 && b64 <= (uint64_t)want + (uint64_t)(hi - lo + m) * k * 16);   // bounded before allocating
+    std::vector<char> blob((size_t)b64);
+    need(fread(blob.data(), 1, blob.size(), f) == blob.size());
+    uint32_t end = 0; need(fread(&end, 4, 1, f) == 1 && end == 0xffffffffu);
     fclose(f);
+    if ((rc = hpf_snapshot_load(h, blob.data(), blob.size()))) die("hpf_snapshot_load (resume)", rc);
     if (root()) env.lerr("resumed from %s at iteration %d", path.c_str(), iter);
   }
 
@@ -661,7 +649,9 @@ int main(int argc, char **argv)
     int port = 29400;
     if (const char *e = getenv("HGAPREC_PORT")) port = atoi(e);
     else if (const char *e2 = getenv("MASTER_PORT")) port = atoi(e2) + 1;   // leave MASTER_PORT to the launcher
-    if (comm.init(rank, world, addr ? addr : "127.0.0.1", port)) {
+    uint64_t nonce = 0;
+    if (const char *e = getenv("HGAPREC_NONCE")) nonce = strtoull(e, nullptr, 16);
+    if (comm.init(rank, world, addr ? addr : "127.0.0.1", port, nonce)) {
       fprintf(stderr, "error: [rank %d] cannot reach rank 0 on port %d\n", rank, port);
       return 1;
     }

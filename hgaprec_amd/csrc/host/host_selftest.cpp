@@ -211,13 +211,13 @@ static void test_state()
 static void test_comm()
 {
   const int world = 4, port = 20000 + (int)(getpid() % 20000);
-  setenv("HGAPREC_NONCE", "c0ffee1234", 1);
+  const uint64_t nonce = 0xc0ffee1234ull;
   std::vector<int> ok(world, 0);
   std::vector<double> sums(world, 0.0), maxs(world, 0.0);
   std::vector<uint32_t> got(world, 0);
   auto body = [&](int rank) {
     Comm c;
-    if (c.init(rank, world, "127.0.0.1", port)) return;
+    if (c.init(rank, world, "127.0.0.1", port, nonce)) return;
     std::vector<double> v(1000);
     for (size_t i = 0; i < v.size(); ++i) v[i] = (double)(rank + 1) * (double)(i + 1);
     if (c.allreduce_sum(v.data(), v.size())) return;
@@ -236,11 +236,8 @@ static void test_comm()
   th.emplace_back(body, 0);
   {
     // a connection that does not know the nonce must be dropped, not given a rank
-    Comm stranger;
-    setenv("HGAPREC_NONCE", "bad", 1);
-    std::thread s([&] { Comm x; (void)x.init(2, world, "127.0.0.1", port); x.close_all(); });
+    std::thread s([&] { Comm x; (void)x.init(2, world, "127.0.0.1", port, 0xbadull); x.close_all(); });
     s.join();
-    setenv("HGAPREC_NONCE", "c0ffee1234", 1);
   }
   for (int r = 1; r < world; ++r) th.emplace_back(body, r);
   for (auto &t : th) t.join();

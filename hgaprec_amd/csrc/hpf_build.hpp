@@ -5,7 +5,7 @@
 // which the reference's serial loop (hgaprec.cc:1340-1345) reaches them, and
 // bit for bit the order of a serial counting sort.
 //
-//   item_hist_kernel      per-item degree (integer atomics: order-free) + range check
+//   colptr_from_sorted    column pointers from the sorted item ids (no atomics)
 //   scan_*_kernel         exclusive scan (3 phases, fixed shape -> same result every run)
 //   radix_count_kernel    per wave-tile digit histogram
 //   radix_scatter_kernel  stable scatter of (key, user, rating): ranks by wave ballots,
@@ -20,18 +20,24 @@
 namespace hpf {
 
 // ---------------------------------------------------------------------
-// per-item degree: cnt[col[j]]++ ; bad[0] |= 1 when an index is out of range
+// column pointers from the SORTED item ids: colptr[i] = first position whose
+// key is >= i.  No atomics: a blockbuster item (C5: one item holds 12 % of all
+// nonzeros) would serialise hundreds of millions of adds on one address --
+// item degrees by atomicAdd took 7.2 ms at C2, longer than the three sort passes.
+// Every position that starts a run of equal keys fills the pointers of its own
+// item and of the empty items before it; the last position closes the array.
 // ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void item_hist_kernel(const uint32_t *col, uint64_t nnz, uint32_t m,
-                                                        uint32_t *cnt, uint32_t *bad)
+__global__ __launch_bounds__(256) void colptr_from_sorted_kernel(const uint32_t *keys, uint64_t nnz, uint32_t m,
+                                                                 int64_t *colptr)
 {
-  bool b = false;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz;
        j += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = col[j];
-    if (c < m) atomicAdd(&cnt[c], 1u); else b = true;
+    const int64_t k = (int64_t)keys[j];
+    const int64_t kp = j ? (int64_t)keys[j - 1] : -1;
+    for (int64_t i = kp + 1; i <= k; ++i) colptr[i] = (int64_t)j;
+    if (j + 1 == nnz)
+      for (int64_t i = k + 1; i <= (int64_t)m; ++i) colptr[i] = (int64_t)nnz;
   }
-  if (b) atomicOr(bad, 1u);
 }
 
 // ---------------------------------------------------------------------
@@ -128,22 +134,30 @@ constexpr int RADIX_DIGITS = 1 << RADIX_BITS;
 constexpr int RADIX_ROUNDS = 64;
 constexpr int RADIX_TILE = RADIX_ROUNDS * 64;
 
+// key_limit / bad: the first pass also checks every item id (< key_limit) on its way
 __global__ __launch_bounds__(256) void radix_count_kernel(const uint32_t *keys, uint64_t nnz, uint32_t shift,
-                                                          uint64_t ntiles, uint64_t *counts)
+                                                          uint64_t ntiles, uint64_t *counts, uint32_t key_limit,
+                                                          uint32_t *bad)
 {
   __shared__ uint32_t hist[4][RADIX_DIGITS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t tile = (uint64_t)blockIdx.x * 4 + wv;
   for (int d = lane; d < RADIX_DIGITS; d += 64) hist[wv][d] = 0;
   __syncthreads();
+  bool oob = false;
   if (tile < ntiles) {
     const uint64_t base = tile * RADIX_TILE;
 #pragma unroll 4
     for (int r = 0; r < RADIX_ROUNDS; ++r) {
       const uint64_t j = base + (uint64_t)r * 64 + lane;
-      if (j < nnz) atomicAdd(&hist[wv][(keys[j] >> shift) & (RADIX_DIGITS - 1)], 1u);
+      if (j < nnz) {
+        const uint32_t key = keys[j];
+        oob |= key >= key_limit;
+        atomicAdd(&hist[wv][(key >> shift) & (RADIX_DIGITS - 1)], 1u);      // LDS, per wave: order-free integers
+      }
     }
   }
+  if (oob) atomicOr(bad, 1u);
   __syncthreads();
   if (tile < ntiles)
     for (int d = lane; d < RADIX_DIGITS; d += 64) counts[(uint64_t)d * ntiles + tile] = hist[wv][d];

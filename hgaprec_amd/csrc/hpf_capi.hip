@@ -92,6 +92,8 @@ struct hpf_handle {
   bool have_csr = false, derived_dirty = true;
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
+  uint32_t sweep_blocks_max = 1024;     // HPF_SWEEP_BLOCKS
+  bool sweep_prefetch = false;          // HPF_SWEEP_PREFETCH
   uint32_t seg_max = 512;
   uint32_t huge_slots = 256, group_slots = 64;  // two-level combine above huge_slots segments (HPF_HUGE_SLOTS)
   bool hot_force = false;               // HPF_HOT_FORCE=1: split even when the estimate says no (tests)
@@ -141,7 +143,10 @@ const char *load_rccl()
   if (g_rccl.lib) return nullptr;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void *lib = nullptr;
-  for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  // a copy this process has already mapped (a host application's, torch's) is THE copy:
+  // two RCCL builds in one process do not survive each other's teardown
+  for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+  if (!lib) for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!lib) return "cannot dlopen librccl.so";
   RcclApi a; a.lib = lib;
   a.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
@@ -267,25 +272,30 @@ bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint3
                 : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
-template <int G>
+template <int G, bool PF>
 bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR>), dim3(blocks), dim3(256), 0, st, a); return true;
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, PF>), dim3(blocks), dim3(256), 0, st, a); return true;
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
   if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
-bool launch_sweep(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+template <bool PF>
+bool launch_sweep_g(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_sweep_r<4>(R, a, blocks, st);
-    case 8:  return launch_sweep_r<8>(R, a, blocks, st);
-    case 16: return launch_sweep_r<16>(R, a, blocks, st);
-    case 32: return launch_sweep_r<32>(R, a, blocks, st);
-    case 64: return launch_sweep_r<64>(R, a, blocks, st);
+    case 4:  return launch_sweep_r<4, PF>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8, PF>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16, PF>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32, PF>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64, PF>(R, a, blocks, st);
   }
   return false;
+}
+bool launch_sweep(int G, int R, bool prefetch, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+{
+  return prefetch ? launch_sweep_g<true>(G, R, a, blocks, st) : launch_sweep_g<false>(G, R, a, blocks, st);
 }
 
 // surfaces a numerical breakdown the kernels flagged (synchronises the stream)
@@ -665,33 +675,25 @@ int device_scan(hpf_handle *h, const IN *in, uint64_t n, uint64_t *out, bool wri
 int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
 {
   int rc;
-  uint32_t *cnt = nullptr, *bad = nullptr;
+  uint32_t *bad = nullptr;
   uint32_t *kbuf[2] = {nullptr, nullptr}, *ut = nullptr; uint8_t *vt = nullptr; uint64_t *counts = nullptr;
   dfree(h->colptr_dev); h->colptr_dev = nullptr;
   dfree(h->it.idx); dfree(h->it.val); h->it.idx = nullptr; h->it.val = nullptr;
   do {
-    if ((rc = dalloc(h, &h->colptr_dev, (size_t)m + 1))) break;
+    if ((rc = dalloc(h, &h->colptr_dev, (size_t)m + 1))) break;          // zeroed: the answer for nnz == 0
     if ((rc = dalloc(h, &h->it.idx, (size_t)nnz))) break;
     if (h->u.val && (rc = dalloc(h, &h->it.val, (size_t)nnz))) break;
     if (nnz == 0) break;
-    if ((rc = dalloc(h, &cnt, m)) || (rc = dalloc(h, &bad, 1))) break;
-    hipLaunchKernelGGL(item_hist_kernel, dim3(grid_for(nnz)), dim3(256), 0, h->stream, h->u.idx, nnz, m, cnt, bad);
-    if ((rc = check_launch(h, "item_hist_kernel"))) break;
-    uint32_t hb = 0;
-    hipError_t e = hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { h->err = std::string("item_hist_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
-    if (hb) { h->err = "item index out of range"; rc = HPF_ERR_INVALID; break; }
-    if ((rc = device_scan<uint32_t>(h, cnt, m, (uint64_t *)h->colptr_dev, true))) break;
-
+    if ((rc = dalloc(h, &bad, 1))) break;
     uint32_t bits = 0;
     while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)m) ++bits;
     const uint32_t P = std::max<uint32_t>(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
     const uint64_t ntiles = (nnz + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t nblk = (uint32_t)((ntiles + 3) / 4);
     if ((rc = dalloc(h, &counts, (size_t)ntiles * RADIX_DIGITS))) break;
-    if (P >= 2 && ((rc = dalloc(h, &kbuf[0], (size_t)nnz)) || (rc = dalloc(h, &ut, (size_t)nnz)))) break;
-    if (P >= 3 && (rc = dalloc(h, &kbuf[1], (size_t)nnz))) break;
+    // keys ping-pong between two buffers; the last pass keeps them too (column pointers)
+    if ((rc = dalloc(h, &kbuf[0], (size_t)nnz))) break;
+    if (P >= 2 && ((rc = dalloc(h, &kbuf[1], (size_t)nnz)) || (rc = dalloc(h, &ut, (size_t)nnz)))) break;
     if (P >= 2 && h->u.val && (rc = dalloc(h, &vt, (size_t)nnz))) break;
     for (uint32_t p = 0; p < P && !rc; ++p) {
       RadixArgs a;
@@ -700,19 +702,31 @@ int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
       a.users_in = p == 0 ? nullptr : (out_final ? ut : h->it.idx);
       a.vals_in = !h->u.val ? nullptr : p == 0 ? h->u.val : (out_final ? vt : h->it.val);
       a.rowptr = h->rowptr_dev; a.n_rows = n;
-      a.keys_out = p + 1 == P ? nullptr : kbuf[p & 1];
+      a.keys_out = kbuf[p & 1];
       a.users_out = out_final ? h->it.idx : ut;
       a.vals_out = !h->u.val ? nullptr : (out_final ? h->it.val : vt);
       a.offsets = counts; a.nnz = nnz; a.ntiles = ntiles; a.shift = p * RADIX_BITS;
-      hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(256), 0, h->stream, a.keys_in, nnz, a.shift, ntiles, counts);
+      hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(256), 0, h->stream, a.keys_in, nnz, a.shift, ntiles, counts,
+                         m, bad);
       if ((rc = check_launch(h, "radix_count_kernel"))) break;
+      if (p == 0) {                                        // every item id was range-checked on the way
+        uint32_t hb = 0;
+        hipError_t e = hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->err = std::string("radix_count_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+        if (hb) { h->err = "item index out of range"; rc = HPF_ERR_INVALID; break; }
+      }
       if ((rc = device_scan<uint64_t>(h, counts, ntiles * RADIX_DIGITS, counts, false))) break;
       hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, h->stream, a);
       rc = check_launch(h, "radix_scatter_kernel");
     }
-    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "CSC build failed on the device"; rc = HPF_ERR_HIP; }
+    if (rc) break;
+    hipLaunchKernelGGL(colptr_from_sorted_kernel, dim3(grid_for(nnz)), dim3(256), 0, h->stream, kbuf[(P - 1) & 1], nnz, m,
+                       h->colptr_dev);
+    if ((rc = check_launch(h, "colptr_from_sorted_kernel"))) break;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "CSC build failed on the device"; rc = HPF_ERR_HIP; }
   } while (0);
-  dfree(cnt); dfree(bad); dfree(kbuf[0]); dfree(kbuf[1]); dfree(ut); dfree(vt); dfree(counts);
+  dfree(bad); dfree(kbuf[0]); dfree(kbuf[1]); dfree(ut); dfree(vt); dfree(counts);
   return rc;
 }
 
@@ -841,7 +855,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
+  if (!launch_sweep(h->swG, h->swR, h->sweep_prefetch, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
@@ -1084,6 +1098,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= 8 && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
         (uint32_t)(g * r) >= h->ld) { h->swG = g; h->swR = r; }
   }
+  if (const char *e = getenv("HPF_SWEEP_PREFETCH")) h->sweep_prefetch = atoi(e) != 0;
+  if (const char *e = getenv("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
   if (const char *e = getenv("HPF_HOT_BYTES")) { long long v = atoll(e); if (v >= 0) h->hot_bytes = (uint64_t)v; }
   if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
   if (const char *e = getenv("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
@@ -1104,7 +1120,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   for (Side *s : sides) {
     const size_t ne = (size_t)s->rows * ld;
     const uint32_t gpb = 256u / (uint32_t)h->swG;         // groups (rows) per block
-    s->sweep_blocks = std::max<uint32_t>(1, std::min<uint32_t>((s->rows + gpb - 1) / gpb, 1024));
+    s->sweep_blocks = std::max<uint32_t>(1, std::min<uint32_t>((s->rows + gpb - 1) / gpb, h->sweep_blocks_max));
     if (s == &h->u) { if ((rc = dalloc(h, &s->S, ne))) return fail(rc); }
     if ((rc = dalloc(h, &s->E, ne))) return fail(rc);
     if ((rc = dalloc(h, &s->L, ne))) return fail(rc);
@@ -1513,6 +1529,127 @@ int hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count)
 int hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t count)
 {
   return get_state_impl(h, which, dev, count, true);
+}
+
+// ---- snapshot: the loop's device state, verbatim -------------------------------
+namespace {
+struct SnapHeader {
+  char magic[8];                        // "HPFSNAP1"
+  uint32_t n_users, n_items, K, ld, hier, bias, w32, iterations;
+  uint32_t side_flags[2];               // bit 0 have_E, 1 have_L, 2 have_prior, 3 w_dirty, 4 l_stale, 5 es_stale,
+                                        // 6 rate_set present, 7 prior_shape_set present
+  uint32_t derived_dirty, pad;
+  uint64_t rate_set_count[2];
+  uint64_t total_bytes;
+};
+struct SnapSection { void *ptr; size_t bytes; };
+
+// every array the iteration reads or the exports are rebuilt from, in a fixed order
+void snapshot_sections(hpf_handle *h, const uint64_t rate_cnt[2], const uint32_t flags[2], std::vector<SnapSection> *out)
+{
+  Side *sides[2] = {&h->u, &h->it};
+  for (int k = 0; k < 2; ++k) {
+    Side &s = *sides[k];
+    const size_t mat = (size_t)s.rows * h->ld * 8, vec = (size_t)s.rows * 8, row = (size_t)h->ld * 8;
+    for (void *p : {(void *)s.S, (void *)s.E, (void *)s.L, s.W}) out->push_back({p, mat});
+    for (double *p : {s.prior_E, s.prior_used, s.prior_rate, s.prior_elog, s.prior_elog_used}) out->push_back({p, vec});
+    out->push_back({s.colsum, row}); out->push_back({s.colsum_used, row});
+    if (flags[k] & 64u) out->push_back({s.rate_set, (size_t)rate_cnt[k] * 8});
+    if (flags[k] & 128u) out->push_back({s.prior_shape_set, vec});
+  }
+}
+uint32_t side_flag_word(const Side &s)
+{
+  return (s.have_E ? 1u : 0u) | (s.have_L ? 2u : 0u) | (s.have_prior ? 4u : 0u) | (s.w_dirty ? 8u : 0u) |
+         (s.l_stale ? 16u : 0u) | (s.es_stale ? 32u : 0u) | (s.rate_set ? 64u : 0u) | (s.prior_shape_set ? 128u : 0u);
+}
+void fill_snap_header(hpf_handle *h, SnapHeader *hd)
+{
+  memset(hd, 0, sizeof *hd);
+  memcpy(hd->magic, "HPFSNAP1", 8);
+  hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
+  hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->w32; hd->iterations = h->iterations;
+  hd->side_flags[0] = side_flag_word(h->u); hd->side_flags[1] = side_flag_word(h->it);
+  hd->derived_dirty = h->derived_dirty;
+  hd->rate_set_count[0] = h->u.rate_set ? h->u.rate_set_count : 0;
+  hd->rate_set_count[1] = h->it.rate_set ? h->it.rate_set_count : 0;
+  std::vector<SnapSection> sec;
+  snapshot_sections(h, hd->rate_set_count, hd->side_flags, &sec);
+  size_t tot = sizeof *hd;
+  for (const SnapSection &x : sec) tot += x.bytes;
+  hd->total_bytes = tot;
+}
+}  // namespace
+
+int hpf_snapshot_size(hpf_handle *h, size_t *bytes)
+{
+  if (!h || !bytes) return HPF_ERR_INVALID;
+  SnapHeader hd; fill_snap_header(h, &hd);
+  *bytes = (size_t)hd.total_bytes;
+  return HPF_OK;
+}
+
+int hpf_snapshot_save(hpf_handle *h, void *host, size_t bytes)
+{
+  if (!h || !host) return HPF_ERR_INVALID;
+  if (h->phase != 0) { h->err = "snapshot inside an iteration"; return HPF_ERR_STATE; }
+  { int rc = check_flags(h); if (rc) return rc; }
+  SnapHeader hd; fill_snap_header(h, &hd);
+  if (bytes != hd.total_bytes) { h->err = "snapshot buffer size differs from hpf_snapshot_size"; return HPF_ERR_INVALID; }
+  memcpy(host, &hd, sizeof hd);
+  std::vector<SnapSection> sec;
+  snapshot_sections(h, hd.rate_set_count, hd.side_flags, &sec);
+  char *p = (char *)host + sizeof hd;
+  for (const SnapSection &x : sec) {
+    int rc = d2h(h, p, x.ptr, x.bytes);
+    if (rc) return rc;
+    p += x.bytes;
+  }
+  return HPF_OK;
+}
+
+int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
+{
+  if (!h || !host || bytes < sizeof(SnapHeader)) return HPF_ERR_INVALID;
+  SnapHeader hd; memcpy(&hd, host, sizeof hd);
+  if (memcmp(hd.magic, "HPFSNAP1", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
+      hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (uint32_t)h->w32) {
+    h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
+  }
+  Side *sides[2] = {&h->u, &h->it};
+  int rc;
+  for (int k = 0; k < 2; ++k) {                           // optional arrays the snapshot carries
+    Side &s = *sides[k];
+    dfree(s.rate_set); s.rate_set = nullptr; s.rate_set_count = 0;
+    if (hd.side_flags[k] & 64u) {
+      const size_t lim = (size_t)s.rows * h->K;
+      if (hd.rate_set_count[k] == 0 || hd.rate_set_count[k] > lim) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
+      if ((rc = dalloc(h, &s.rate_set, (size_t)hd.rate_set_count[k]))) return rc;
+      s.rate_set_count = (size_t)hd.rate_set_count[k];
+    }
+    if ((hd.side_flags[k] & 128u) && !s.prior_shape_set && (rc = dalloc(h, &s.prior_shape_set, s.rows))) return rc;
+  }
+  std::vector<SnapSection> sec;
+  snapshot_sections(h, hd.rate_set_count, hd.side_flags, &sec);
+  size_t tot = sizeof hd;
+  for (const SnapSection &x : sec) tot += x.bytes;
+  if (tot != bytes) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
+  drop_graph(h);
+  const char *p = (const char *)host + sizeof hd;
+  for (const SnapSection &x : sec) {
+    if ((rc = h2d(h, x.ptr, p, x.bytes))) return rc;
+    p += x.bytes;
+  }
+  for (int k = 0; k < 2; ++k) {
+    Side &s = *sides[k]; const uint32_t f = hd.side_flags[k];
+    s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
+  }
+  h->derived_dirty = hd.derived_dirty != 0;
+  h->iterations = hd.iterations;
+  h->phase = 0;
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return HPF_OK;
 }
 
 int hpf_iterate(hpf_handle *h, int n_iters)

@@ -152,6 +152,16 @@ int  hpf_get_state(hpf_handle *h, hpf_state which, double *host, size_t count);
 int  hpf_set_state_device(hpf_handle *h, hpf_state which, const double *dev, size_t count);
 int  hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t count);
 
+/* Snapshot (extension; the reference has no training resume: `-load` is parsed
+ * and never consulted, main.cc:137-140): the loop's whole device state as one
+ * opaque host blob -- the gathered matrices W, raw sums, expectations, xi/eta
+ * vectors, column sums and the bookkeeping flags, verbatim.  A handle of the same
+ * shape that loads it continues with IDENTICAL bits (hpf_set_state(ELOG) would
+ * re-derive W and round differently).  Call between iterations. */
+int  hpf_snapshot_size(hpf_handle *h, size_t *bytes);
+int  hpf_snapshot_save(hpf_handle *h, void *host, size_t bytes);
+int  hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes);
+
 /* replaces: n_iters passes of steps A-F of HGAPRec::vb_hier
  * (hgaprec.cc:1340-1414), or of vb (927-956) / vb_bias (1226-1272) without
  * -hier.  With n_ranks > 1 it needs hpf_comm_init and runs the overlapped
@@ -260,7 +270,7 @@ typedef struct {
   uint32_t user_segments, user_long_rows, user_huge_rows;
   uint32_t item_segments, item_long_rows, item_huge_rows;
   uint32_t phi_G, phi_R, phi_V;      /* lanes per nonzero, loads per lane, doubles per load */
-  uint32_t sweep_G, sweep_R;
+  uint32_t sweep_G, sweep_R;         /* row sweep: lanes per row, columns per lane */
   uint32_t ld;                       /* row stride of the device matrices, doubles */
   uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
   uint32_t reserved[3];

@@ -173,6 +173,48 @@ def test_graph_replay_equals_eager_launches(orc, monkeypatch, bias):
     assert tms[0]["iterations"] == tms[1]["iterations"] == 6
 
 
+@pytest.mark.parametrize("hier,bias", [(True, True), (False, False)])
+def test_snapshot_restore_continues_bit_identically(orc, hier, bias):
+    # hpf_snapshot_save / _load: the loop's device arrays verbatim.  A second handle that
+    # loads the blob after 3 iterations must stay bit-identical to the uninterrupted
+    # one -- state, held-out likelihood and ELBO -- which hpf_set_state cannot give
+    # (it re-derives W from Elog and re-sums the expectations).
+    from hgaprec_amd.capi import Hpf, HpfError
+    n, m, K = 400, 300, 20
+    M, A = _run_pair(orc, n, m, K, 9000, hier, bias, False, 8, seed=14)
+    A.iterate(3)
+    blob = A.snapshot()
+    B = Hpf(n, m, K, hier=hier, bias=bias)
+    rowptr, col, val = make_problem(n, m, 9000, 14)
+    B.upload_csr(rowptr, col, val)
+    B.restore(blob)
+    A.iterate(5); B.iterate(5)
+    for w in compare_states(hier, bias):
+        assert np.array_equal(A.get_state(w), B.get_state(w)), w
+    hu, hi, hy = heldout_pairs(n, m, 500, seed=2)
+    assert A.heldout_ll(hu, hi, hy) == B.heldout_ll(hu, hi, hy)
+    assert A.elbo() == B.elbo()
+    M.iterate(8)
+    assert rel_err(B.get_state("BETA_E"), M.state("BETA_E")) < RTOL
+    # a blob of another shape, a truncated blob and a damaged header are refused
+    C2 = Hpf(n, m, K + 1, hier=hier, bias=bias)
+    with pytest.raises(HpfError):
+        C2.restore(blob)
+    with pytest.raises(HpfError):
+        B.restore(blob[:-8])
+    bad = blob.copy(); bad[0] ^= 1
+    with pytest.raises(HpfError):
+        B.restore(bad)
+    # before the first iteration too: the start state itself round-trips
+    M2, D = _run_pair(orc, n, m, K, 9000, hier, bias, False, 2, seed=14)
+    E = Hpf(n, m, K, hier=hier, bias=bias)
+    E.upload_csr(rowptr, col, val)
+    E.restore(D.snapshot())
+    D.iterate(2); E.iterate(2)
+    assert np.array_equal(D.get_state("THETA_E"), E.get_state("THETA_E"))
+    assert np.array_equal(D.get_state("THETA_RATE"), E.get_state("THETA_RATE"))
+
+
 def test_twenty_iterations_within_contract(orc):
     # the north_star contract itself: 1e-4 relative on the factors
     M, D = _run_pair(orc, 500, 400, 20, 15000, True, False, False, 20, seed=8)
