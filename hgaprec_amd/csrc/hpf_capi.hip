@@ -92,8 +92,7 @@ struct hpf_handle {
   bool have_csr = false, derived_dirty = true;
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
-  uint32_t sweep_blocks_max = 1024;     // HPF_SWEEP_BLOCKS
-  bool sweep_prefetch = false;          // HPF_SWEEP_PREFETCH
+  uint32_t sweep_blocks_max = 2048;     // 8 waves per SIMD (HPF_SWEEP_BLOCKS); 1024 -> 2048: C2 user sweep 0.587 -> 0.544 ms
   uint32_t seg_max = 512;
   uint32_t huge_slots = 256, group_slots = 64;  // two-level combine above huge_slots segments (HPF_HUGE_SLOTS)
   bool hot_force = false;               // HPF_HOT_FORCE=1: split even when the estimate says no (tests)
@@ -272,30 +271,25 @@ bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint3
                 : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
-template <int G, bool PF>
+template <int G>
 bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, PF>), dim3(blocks), dim3(256), 0, st, a); return true;
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR>), dim3(blocks), dim3(256), 0, st, a); return true;
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
   if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
-template <bool PF>
-bool launch_sweep_g(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_sweep(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_sweep_r<4, PF>(R, a, blocks, st);
-    case 8:  return launch_sweep_r<8, PF>(R, a, blocks, st);
-    case 16: return launch_sweep_r<16, PF>(R, a, blocks, st);
-    case 32: return launch_sweep_r<32, PF>(R, a, blocks, st);
-    case 64: return launch_sweep_r<64, PF>(R, a, blocks, st);
+    case 4:  return launch_sweep_r<4>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64>(R, a, blocks, st);
   }
   return false;
-}
-bool launch_sweep(int G, int R, bool prefetch, const SweepArgs &a, uint32_t blocks, hipStream_t st)
-{
-  return prefetch ? launch_sweep_g<true>(G, R, a, blocks, st) : launch_sweep_g<false>(G, R, a, blocks, st);
 }
 
 // surfaces a numerical breakdown the kernels flagged (synchronises the stream)
@@ -855,7 +849,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->swG, h->swR, h->sweep_prefetch, a, s.sweep_blocks, h->stream)) {
+  if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
@@ -1098,7 +1092,6 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= 8 && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
         (uint32_t)(g * r) >= h->ld) { h->swG = g; h->swR = r; }
   }
-  if (const char *e = getenv("HPF_SWEEP_PREFETCH")) h->sweep_prefetch = atoi(e) != 0;
   if (const char *e = getenv("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
   if (const char *e = getenv("HPF_HOT_BYTES")) { long long v = atoll(e); if (v >= 0) h->hot_bytes = (uint64_t)v; }
   if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
