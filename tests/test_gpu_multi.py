@@ -245,6 +245,34 @@ def test_two_gpus_bench_strong_scaling_line():
     assert sum(nn) == d["config"]["nnz_total"] and abs(nn[0] - nn[1]) < 0.05 * sum(nn)
 
 
+def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo():
+    """bench.py's strong-scaling path with two REAL ranks sharing GPU 0 (gloo carries the
+    all-reduce; RCCL refuses two ranks on one device): each rank generates only its
+    nnz-balanced user range of the same C3-shaped matrix (cut to 0.5 %), the ranks
+    cross-check the cut, and the line must account for every nonzero of the whole matrix."""
+    import torch
+    from hgaprec_amd import synth
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "0.005",
+                        "--backend", "gloo", "--same-device"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["replica_check"] == "ok" and d["self_check"]["ok"]
+    assert d["config"]["workload"].startswith("C3")
+    cfg = synth.CONFIGS["C3"]
+    n, m, nnz = int(cfg["n"] * 0.005), int(cfg["m"] * 0.005), int(cfg["nnz"] * 0.005)
+    rp, _, _ = synth.generate_device(n, m, nnz, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"],
+                                     device=torch.device("cuda", 0))
+    assert d["config"]["nnz_total"] == int(rp[-1])                  # the two shards ARE the one matrix
+    assert d["config"]["users_total"] == n
+    pr = d["per_rank"]
+    assert pr[0]["users"] + pr[1]["users"] == n and abs(pr[0]["nnz"] - pr[1]["nnz"]) < 0.05 * int(rp[-1])
+    assert all(x["phi_item_ms"] > 0 and x["exchange_wait_ms"] >= 0 for x in pr)
+
+
 def test_one_gpu_bench_takes_the_distributed_path():
     """the N > 1 code path of bench.py (process group, bound exchange tensor, the
     overlapped all-reduces) on one rank -- HPF_BENCH_FORCE_DIST=1 -- at 1 % of C2"""
