@@ -83,7 +83,7 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
 
 def kernels_sha():
     h = hashlib.sha256()
-    for f in ("hpf_kernels.hpp", "hpf_capi.hip"):
+    for f in ("hpf_kernels.hpp",):                    # the kernels' source: what the traffic was measured on
         h.update((ROOT / "hgaprec_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -91,7 +91,7 @@ def kernels_sha():
 def measured_traffic(config, kern):
     """HBM-side bytes per launch from the PMC passes kept in profiles/traffic.json
     (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md).  Only quoted when the
-    file was measured on THIS kernel source (sha of the two kernel files)."""
+    file was measured on THIS kernel source (sha of hpf_kernels.hpp)."""
     tf = ROOT / "profiles" / "traffic.json"
     if not tf.exists():
         return None, "no profiles/traffic.json"

@@ -31,4 +31,8 @@ HPF_LD_ROUND=16 $BENCH > $OUT/bench_ld16.json 2> $OUT/bench_ld16.log
 python bench.py --config C4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.log
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --host-handover > $OUT/bench_c3_full_1gpu.json 2> $OUT/bench_c3_full_1gpu.log
 python bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_full_1gpu.json 2> $OUT/bench_c5_full_1gpu.log
+# 7. what one of 8 GPUs would hold of C3 (1.25M users x ALL 1M items, 1.25e8 nnz): the compute side of the 8-GPU estimate
+python bench.py --config C3 --n 1250000 --nnz 125000000 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c3_shard_like_1gpu.json 2> $OUT/bench_c3_shard_like_1gpu.log
+# 8. report-step operations at C2 (held-out LL, ELBO, ranking evaluation)
+python tools/bench_report_step.py C2 > $OUT/report_step_c2.json 2> $OUT/report_step_c2.log
 ls -la $OUT
