@@ -10,12 +10,15 @@
 //   radix_count_kernel    per wave-tile digit histogram
 //   radix_scatter_kernel  stable scatter of (key, user, rating): ranks by wave ballots,
 //                         per-wave running digit counters in LDS, no atomics on order
+//   seg_plan / seg_fill   the phi passes' work lists (segments, long rows, two-level groups)
 //   repack_*_kernel       dense [rows x cols] <-> padded [rows x ld] column block
 //
 // All integer / byte work, HBM-bound; nothing here is shaped for MFMA.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "hpf_kernels.hpp"      // Seg, LongRow
 
 namespace hpf {
 
@@ -234,6 +237,85 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(RadixArgs a)
       if (a.keys_out) a.keys_out[p] = key;
       a.users_out[p] = user;
       if (a.vals_out) a.vals_out[p] = (uint8_t)val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// Work lists of a phi pass, cut on the device from a row-pointer array:
+// a row of deg <= seg_max nonzeros is one segment that writes its shape row
+// itself; a longer row is cut into ceil(deg / seg_max) segments that write
+// partial slots; rows with more than huge_slots segments are combined in two
+// levels (groups of group_slots partials, then the group sums).
+//   seg_plan_kernel   per row: the five counters whose exclusive scans place its output
+//   seg_fill_kernel   per row: its Seg / LongRow records at the scanned offsets
+// Also validates the row pointers (monotone, first one 0).
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowptr_check_kernel(const int64_t *ptr, uint32_t rows, uint32_t *bad)
+{
+  bool b = false;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    b |= ptr[r + 1] < ptr[r];
+  if (b) atomicOr(bad, 1u);
+}
+
+struct SegPlan {            // per-row counters (scanned in place into offsets)
+  uint64_t *nseg, *nslot, *nlong, *nhuge, *ngroup;
+};
+
+__global__ __launch_bounds__(256) void seg_plan_kernel(const int64_t *ptr, uint32_t rows, uint32_t seg_max,
+                                                       uint32_t huge_slots, uint32_t group_slots, SegPlan p,
+                                                       uint32_t *bad)
+{
+  bool b = false;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const int64_t a = ptr[r], e = ptr[r + 1];
+    b |= e < a || (r == 0 && a != 0);
+    const uint64_t deg = e > a ? (uint64_t)(e - a) : 0;
+    const bool is_long = deg > seg_max;
+    const uint64_t ns = is_long ? (deg + seg_max - 1) / seg_max : 1;
+    const bool is_huge = is_long && ns > huge_slots;
+    p.nseg[r] = ns;
+    p.nslot[r] = is_long ? ns : 0;
+    p.nlong[r] = (is_long && !is_huge) ? 1 : 0;
+    p.nhuge[r] = is_huge ? 1 : 0;
+    p.ngroup[r] = is_huge ? (ns + group_slots - 1) / group_slots : 0;
+  }
+  if (b) atomicOr(bad, 1u);
+}
+
+__global__ __launch_bounds__(256) void seg_fill_kernel(const int64_t *ptr, uint32_t rows, uint32_t seg_max,
+                                                       uint32_t huge_slots, uint32_t group_slots, SegPlan off,
+                                                       Seg *segs, LongRow *longs, LongRow *huges, LongRow *groups)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const int64_t a = ptr[r];
+    const uint64_t deg = (uint64_t)(ptr[r + 1] - a);
+    const bool is_long = deg > seg_max;
+    const uint64_t ns = is_long ? (deg + seg_max - 1) / seg_max : 1;
+    const uint64_t so = off.nseg[r], po = off.nslot[r];
+    for (uint64_t k = 0; k < ns; ++k) {
+      Seg s;
+      s.start = a + (int64_t)(k * seg_max);
+      s.row = r;
+      s.len = is_long ? (uint32_t)((deg - k * seg_max < seg_max) ? deg - k * seg_max : seg_max) : (uint32_t)deg;
+      s.pslot = is_long ? (int32_t)(po + k) : -1;
+      s.pad = 0;
+      segs[so + k] = s;
+    }
+    if (!is_long) continue;
+    if (ns <= huge_slots) {
+      LongRow lr; lr.row = r; lr.first_slot = (uint32_t)po; lr.nslots = (uint32_t)ns; lr.pad = 0;
+      longs[off.nlong[r]] = lr;
+    } else {
+      const uint64_t go = off.ngroup[r], ng = (ns + group_slots - 1) / group_slots;
+      LongRow top; top.row = r; top.first_slot = (uint32_t)go; top.nslots = (uint32_t)ng; top.pad = 0;
+      huges[off.nhuge[r]] = top;
+      for (uint64_t g = 0; g < ng; ++g) {
+        LongRow gr; gr.row = (uint32_t)(go + g); gr.first_slot = (uint32_t)(po + g * group_slots);
+        gr.nslots = (uint32_t)((ns - g * group_slots < group_slots) ? ns - g * group_slots : group_slots); gr.pad = 0;
+        groups[go + g] = gr;
+      }
     }
   }
 }

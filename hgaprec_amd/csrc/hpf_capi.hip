@@ -663,6 +663,58 @@ int device_scan(hpf_handle *h, const IN *in, uint64_t n, uint64_t *out, bool wri
   return rc;
 }
 
+// Work lists of one side cut on the device from its row pointers (dptr, in HBM): nothing of
+// size O(rows) or O(nnz) crosses PCIe.  Same lists, in the same order, as the host loop of
+// upload_side_work (which stays for the hot/cold experiment that reorders nonzeros).
+int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
+{
+  for (int p = 0; p < 2; ++p) {
+    dfree(s.segs[p]); dfree(s.longrows[p]); dfree(s.grouprows[p]); dfree(s.hugerows[p]);
+    s.segs[p] = nullptr; s.longrows[p] = s.grouprows[p] = s.hugerows[p] = nullptr;
+    s.nseg[p] = s.nlong[p] = s.ngroup[p] = s.nhuge[p] = 0;
+  }
+  dfree(s.partial); dfree(s.partial2);
+  s.partial = nullptr; s.partial2 = nullptr;
+  s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0; s.npartial = 0; s.npartial2 = 0;
+  if (rows == 0) return HPF_OK;
+  int rc = HPF_OK;
+  uint64_t *cnt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t *bad = nullptr;
+  do {
+    for (int k = 0; k < 5 && !rc; ++k) rc = dalloc(h, &cnt[k], (size_t)rows + 1);
+    if (rc || (rc = dalloc(h, &bad, 1))) break;
+    SegPlan pl = {cnt[0], cnt[1], cnt[2], cnt[3], cnt[4]};
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(grid_for(rows)), dim3(256), 0, h->stream, dptr, rows, h->seg_max,
+                       h->huge_slots, h->group_slots, pl, bad);
+    if ((rc = check_launch(h, "seg_plan_kernel"))) break;
+    for (int k = 0; k < 5 && !rc; ++k) rc = device_scan<uint64_t>(h, cnt[k], rows, cnt[k], true);
+    if (rc) break;
+    uint64_t tot[5]; uint32_t hb = 0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 5 && e == hipSuccess; ++k)
+      e = hipMemcpyAsync(&tot[k], cnt[k] + rows, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = std::string("seg_plan_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
+    if (hb) { h->err = "row pointers must start at 0 and be monotone"; rc = HPF_ERR_INVALID; break; }
+    if (tot[0] > 0xffffffffull || tot[1] > 0x7fffffffull) { h->err = "too many segments for 32-bit work lists"; rc = HPF_ERR_UNSUPPORTED; break; }
+    s.nseg[0] = (uint32_t)tot[0]; s.npartial = (uint32_t)tot[1]; s.nlong[0] = (uint32_t)tot[2];
+    s.nhuge[0] = (uint32_t)tot[3]; s.ngroup[0] = s.npartial2 = (uint32_t)tot[4];
+    if ((rc = dalloc(h, &s.segs[0], s.nseg[0])) || (rc = dalloc(h, &s.longrows[0], s.nlong[0]))) break;
+    if (s.ngroup[0] && ((rc = dalloc(h, &s.grouprows[0], s.ngroup[0])) || (rc = dalloc(h, &s.hugerows[0], s.nhuge[0])))) break;
+    if ((rc = dalloc(h, &s.segs[1], 0)) || (rc = dalloc(h, &s.longrows[1], 0))) break;
+    hipLaunchKernelGGL(seg_fill_kernel, dim3(grid_for(rows)), dim3(256), 0, h->stream, dptr, rows, h->seg_max,
+                       h->huge_slots, h->group_slots, pl, s.segs[0], s.longrows[0], s.hugerows[0], s.grouprows[0]);
+    if ((rc = check_launch(h, "seg_fill_kernel"))) break;
+    if ((rc = dalloc(h, &s.partial, (size_t)s.npartial * h->ld))) break;
+    if (s.npartial2 && (rc = dalloc(h, &s.partial2, (size_t)s.npartial2 * h->ld))) break;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "work-list build failed on the device"; rc = HPF_ERR_HIP; }
+  } while (0);
+  for (int k = 0; k < 5; ++k) dfree(cnt[k]);
+  dfree(bad);
+  return rc;
+}
+
 // Item-major view of the ratings, built in HBM: h->u.idx / h->u.val (CSR order)
 // and h->rowptr_dev are in place; fills h->colptr_dev, h->it.idx, h->it.val.
 // Stable LSD radix sort on the item id => users ascending inside an item.
@@ -1274,16 +1326,25 @@ int hpf_exchange_buffer(hpf_handle *h, void **dev, size_t *count)
 }
 
 // common tail of both uploads: h->u.idx / h->u.val / h->rowptr_dev are in place
-static int finish_upload(hpf_handle *h, const int64_t *rowptr /* host */, uint64_t nnz)
+static int finish_upload(hpf_handle *h, uint64_t nnz)
 {
   const uint32_t n = h->u.rows, m = h->it.rows;
   int rc;
   if ((rc = build_csc_device(h, n, m, nnz))) return rc;
-  std::vector<int64_t> colptr((size_t)m + 1, 0);
-  if ((rc = d2h(h, colptr.data(), h->colptr_dev, ((size_t)m + 1) * 8))) return rc;
-  if ((uint64_t)colptr[m] != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
-  if ((rc = upload_side_work(h, h->u, rowptr, n, nnz, colptr.data(), m))) return rc;
-  if ((rc = upload_side_work(h, h->it, colptr.data(), m, nnz, rowptr, n))) return rc;
+  int64_t last = 0;
+  HIPCHK(h, hipMemcpyAsync(&last, h->colptr_dev + m, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((uint64_t)last != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
+  if (h->hot_bytes == 0) {
+    if ((rc = device_side_work(h, h->u, h->rowptr_dev, n))) return rc;
+    if ((rc = device_side_work(h, h->it, h->colptr_dev, m))) return rc;
+  } else {                                       // hot/cold experiment: reorders nonzeros on the host
+    std::vector<int64_t> rowptr((size_t)n + 1), colptr((size_t)m + 1);
+    if ((rc = d2h(h, rowptr.data(), h->rowptr_dev, ((size_t)n + 1) * 8))) return rc;
+    if ((rc = d2h(h, colptr.data(), h->colptr_dev, ((size_t)m + 1) * 8))) return rc;
+    if ((rc = upload_side_work(h, h->u, rowptr.data(), n, nnz, colptr.data(), m))) return rc;
+    if ((rc = upload_side_work(h, h->it, colptr.data(), m, nnz, rowptr.data(), n))) return rc;
+  }
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nnz = nnz; h->have_csr = true;
@@ -1322,7 +1383,7 @@ int hpf_upload_csr(hpf_handle *h, const int64_t *rowptr, const uint32_t *col, co
   if ((rc = h2d(h, h->u.idx, col, nnz * 4))) return rc;
   if (val && (rc = h2d(h, h->u.val, val, nnz))) return rc;
   if ((rc = h2d(h, h->rowptr_dev, rowptr, ((size_t)n + 1) * 8))) return rc;
-  return finish_upload(h, rowptr, nnz);
+  return finish_upload(h, nnz);
 }
 
 int hpf_upload_csr_device(hpf_handle *h, const int64_t *d_rowptr, const uint32_t *d_col, const uint8_t *d_val)
@@ -1330,17 +1391,32 @@ int hpf_upload_csr_device(hpf_handle *h, const int64_t *d_rowptr, const uint32_t
   if (!h || !d_rowptr) return HPF_ERR_INVALID;
   const uint32_t n = h->u.rows;
   int rc;
-  std::vector<int64_t> rowptr((size_t)n + 1);
-  if ((rc = d2h(h, rowptr.data(), d_rowptr, ((size_t)n + 1) * 8))) return rc;
-  if ((rc = check_rowptr(h, rowptr.data(), n))) return rc;
-  const uint64_t nnz = (uint64_t)rowptr[n];
+  // only the two ends of the row pointers come to the host; monotonicity is checked on the
+  // device while the work lists are cut (seg_plan_kernel)
+  int64_t ends[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(&ends[0], d_rowptr, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&ends[1], d_rowptr + n, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (ends[0] != 0) { h->err = "rowptr[0] must be 0"; return HPF_ERR_INVALID; }
+  if (ends[1] < 0) { h->err = "rowptr not monotone"; return HPF_ERR_INVALID; }
+  const uint64_t nnz = (uint64_t)ends[1];
   if (nnz && !d_col) return HPF_ERR_INVALID;
   if ((rc = alloc_user_nonzeros(h, nnz, d_val != nullptr))) return rc;
   if (nnz) HIPCHK(h, hipMemcpyAsync(h->u.idx, d_col, nnz * 4, hipMemcpyDeviceToDevice, h->stream));
   if (nnz && d_val) HIPCHK(h, hipMemcpyAsync(h->u.val, d_val, nnz, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->rowptr_dev, d_rowptr, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return finish_upload(h, rowptr.data(), nnz);
+  // the sort's first pass bisects the row pointers: they must be monotone BEFORE it runs
+  {
+    uint32_t *bad = nullptr; uint32_t hb = 0;
+    if ((rc = dalloc(h, &bad, 1))) return rc;
+    hipLaunchKernelGGL(rowptr_check_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, h->rowptr_dev, n, bad);
+    hipError_t e = hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(bad);
+    if (e != hipSuccess) { h->err = std::string("rowptr check: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+    if (hb) { h->err = "rowptr not monotone"; return HPF_ERR_INVALID; }
+  }
+  return finish_upload(h, nnz);
 }
 
 int hpf_get_csc(hpf_handle *h, int64_t *colptr, uint32_t *users, uint8_t *vals)

@@ -74,3 +74,18 @@ def test_cli_usage_and_unknown_option(tmp_path):
     assert r.returncode != 0 and "error: unknown option -bogus" in r.stdout
     r = subprocess.run([exe, "-dir", "x", "-nmf"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 2 and "outside the MI355X hot-path build" in r.stderr
+
+
+def test_cli_refuses_the_jacobi_ordering_it_does_not_build(tmp_path):
+    """-novb only changes the reference in vb_bias() (-bias without -hier,
+    hgaprec.cc:1276-1297): both rate updates there use the previous iteration's
+    expectations.  That ordering is not built; the flag must be refused loudly, not
+    accepted and run in the default order.  With -hier (or without -bias) the
+    reference never reads the flag, so it stays accepted."""
+    exe = str(ROOT / "hgaprec_amd" / "hgaprec")
+    r = subprocess.run([exe, "-dir", "x", "-n", "5", "-m", "5", "-k", "2", "-bias", "-novb"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "-novb" in r.stderr and "outside the MI355X hot-path build" in r.stderr
+    r = subprocess.run([exe, "-dir", str(tmp_path / "missing"), "-n", "5", "-m", "5", "-k", "2", "-hier", "-novb"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert "outside the MI355X hot-path build" not in r.stderr      # goes on (and fails later: no GPU / no data)
