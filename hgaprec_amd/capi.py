@@ -303,6 +303,16 @@ class Hpf:
         return p.value, n.value
 
     def bind_exchange_buffer(self, dev_ptr: int, count: int):
+        """dev_ptr: device memory the caller owns (e.g. a torch tensor's data_ptr()).  The
+        library clears it on ITS stream, so no other stream may still be using that memory:
+        a torch caching-allocator block can be one that kernels queued earlier on torch's
+        stream are still working in (torch only orders reuse on the same stream) -- found the
+        hard way in tools/emulate_shards.py, where the clear landed in the temporaries of a
+        generator that was still running.  If torch is loaded, quiesce it first."""
+        import sys
+        t = sys.modules.get("torch")
+        if t is not None and t.cuda.is_initialized():
+            t.cuda.synchronize()
         self._check(self.lib.hpf_bind_exchange_buffer(self._h, C.c_void_p(dev_ptr), count))
 
     def exchange_read(self) -> np.ndarray:

@@ -196,7 +196,10 @@ int  hpf_iterate_local_sweep(hpf_handle *h);
  * handle's stream ... */
 int  hpf_exchange_buffer(hpf_handle *h, void **device_ptr, size_t *count);
 /* optional: make the handle use caller-owned device memory (>= count doubles,
- * 16-byte aligned) as the exchange buffer; call before hpf_upload_csr */
+ * 16-byte aligned) as the exchange buffer; call before hpf_upload_csr.  The
+ * buffer is cleared on the handle's stream: no work queued on another stream
+ * may still be using that memory (a caching allocator can hand out a block
+ * that earlier kernels of ITS stream are not done with). */
 int  hpf_bind_exchange_buffer(hpf_handle *h, void *device_ptr, size_t count);
 /* ... then the replicated item sweep (C, D-item, F) on every rank. */
 int  hpf_iterate_global(hpf_handle *h);
