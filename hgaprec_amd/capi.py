@@ -246,6 +246,7 @@ class Hpf:
     def get_state_device(self, which: str, device=None):
         import torch
         out = torch.empty(self.state_shape(which), dtype=torch.float64, device=device or "cuda")
+        torch.cuda.synchronize(out.device)       # the block may still be in use by work queued on torch's stream
         self._check(self.lib.hpf_get_state_device(self._h, STATE[which], C.c_void_p(out.data_ptr()), out.numel()))
         return out
 
