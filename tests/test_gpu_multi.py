@@ -245,6 +245,64 @@ def test_two_gpus_bench_strong_scaling_line():
     assert sum(nn) == d["config"]["nnz_total"] and abs(nn[0] - nn[1]) < 0.05 * sum(nn)
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_range_generated_shards_equal_the_unsharded_run(world):
+    """What `bench.py --gpus N` does, minus the wire: the users of a C3-shaped matrix
+    (1 % scale) cut into `world` nnz-balanced ranges on the PLANNED degrees, every shard
+    generated on its own from the counter-hash generator, handles with bound exchange
+    tensors all resident, exchange buffers summed in place of the all-reduce.  After 3
+    iterations every shard must agree with the unsharded run to 1e-10 -- the check the
+    bench's own replica / mass checks cannot make (they hold for any consistent data)."""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    from hgaprec_amd.dist import partition_users
+    cfg = synth.CONFIGS["C3"]
+    n, m, nnz, K = cfg["n"] // 100, cfg["m"] // 100, cfg["nnz"] // 100, cfg["K"]
+    dev = torch.device("cuda", 0)
+    deg = synth.degrees(n, m, nnz, cfg["alpha_u"], cfg["seed"], dev)
+    planned = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=planned[1:])
+
+    def make(a, b, nr, r):
+        rp, c, v = synth.generate_device(n, m, nnz, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev,
+                                         user_range=(a, b), deg=deg)
+        D = Hpf(b - a, m, K, hier=True, n_ranks=nr, rank=r, n_users_total=n)
+        x = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
+        D.bind_exchange_buffer(x.data_ptr(), x.numel())          # no torch.cuda.synchronize() here on purpose
+        D.upload_csr_device(rp, c, v)
+        st = synth.initial_state_device(b - a, K, 1, dev, row0=a)
+        D.set_state_device("THETA_E", st["E"]); D.set_state_device("THETA_ELOG", st["Elog"])
+        st = synth.initial_state_device(m, K, 2, dev)
+        D.set_state_device("BETA_E", st["E"]); D.set_state_device("BETA_ELOG", st["Elog"])
+        D.set_state_device("XI_E", synth.initial_state_device(b - a, K, 3, dev, prior_v=K, row0=a)["E"])
+        D.set_state_device("ETA_E", synth.initial_state_device(m, K, 4, dev, prior_v=K)["E"])
+        return D, x, int(rp[-1])
+
+    full, _, nnz_full = make(0, n, 1, 0)
+    full.iterate(3)
+    ref_t, ref_b = full.get_state_device("THETA_E", dev), full.get_state_device("BETA_E", dev)
+    full.close()
+    parts = partition_users(planned.cpu().numpy(), world)
+    shards = [make(a, b, world, r) for r, (a, b) in enumerate(parts)]
+    assert sum(s[2] for s in shards) == nnz_full
+    assert max(s[2] for s in shards) < 1.02 * nnz_full / world
+    for _ in range(3):
+        for S, _, _ in shards:
+            S.iterate_local_items(); S.iterate_local_users(); S.synchronize()
+        tot = sum(x for _, x, _ in shards)
+        for _, x, _ in shards:
+            x.copy_(tot)
+        torch.cuda.synchronize()
+        for S, _, _ in shards:
+            S.iterate_global()
+    for (a, b), (S, _, _) in zip(parts, shards):
+        t = S.get_state_device("THETA_E", dev)
+        assert float(((t - ref_t[a:b]).abs() / ref_t[a:b]).max()) < 1e-10
+        assert float(((S.get_state_device("BETA_E", dev) - ref_b).abs() / ref_b).max()) < 1e-10
+        S.close()
+
+
 def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo():
     """bench.py's strong-scaling path with two REAL ranks sharing GPU 0 (gloo carries the
     all-reduce; RCCL refuses two ranks on one device): each rank generates only its
