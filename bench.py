@@ -349,7 +349,11 @@ def main():
 
     handover = {"generate_s": round(t_gen, 3), "upload_csr_device_s": round(t_upload, 3),
                 "set_state_device_s": round(t_state, 3)}
-    if args.host_handover and rank == 0:
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    second_handle_bytes = (n_loc + m) * (K + 2) * 8 * 4 + nnz_loc * 12          # a whole second handle beside the first
+    if args.host_handover and rank == 0 and second_handle_bytes > 0.8 * free_b:
+        handover["host_handover_skipped"] = "a second resident handle does not fit beside the first"
+    elif args.host_handover and rank == 0:
         # PCIe-inclusive set-up for a caller that holds host buffers (never part of `value`)
         rp_h, col_h = rowptr.cpu().numpy(), col.cpu().numpy().view(np.uint32)
         val_h = None if val is None else val.cpu().numpy()
