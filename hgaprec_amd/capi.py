@@ -86,6 +86,16 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = Path(path) if path else LIB_PATH
+    # One HIP runtime per process.  libhpf_hip.so is linked against the system ROCm
+    # (libamdhip64.so.7); a torch wheel brings its own copy of the HIP and HSA runtimes.
+    # If the system copy is mapped first and torch is imported later, the process ends up
+    # with TWO HSA runtimes and torch finds "No HIP GPUs"; the other way round the library's
+    # dependency resolves to the copy torch already mapped (same SONAME).  So in a process
+    # that may use torch at all, torch goes first.  (C/C++ callers are not concerned.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not p.exists():
         raise HpfError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

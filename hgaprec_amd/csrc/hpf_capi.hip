@@ -723,6 +723,7 @@ int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
   int rc;
   uint32_t *bad = nullptr;
   uint32_t *kbuf[2] = {nullptr, nullptr}, *ut = nullptr; uint8_t *vt = nullptr; uint64_t *counts = nullptr;
+  unsigned char *pool = nullptr;
   dfree(h->colptr_dev); h->colptr_dev = nullptr;
   dfree(h->it.idx); dfree(h->it.val); h->it.idx = nullptr; h->it.val = nullptr;
   do {
@@ -736,11 +737,20 @@ int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
     const uint32_t P = std::max<uint32_t>(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
     const uint64_t ntiles = (nnz + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t nblk = (uint32_t)((ntiles + 3) / 4);
-    if ((rc = dalloc(h, &counts, (size_t)ntiles * RADIX_DIGITS))) break;
-    // keys ping-pong between two buffers; the last pass keeps them too (column pointers)
-    if ((rc = dalloc(h, &kbuf[0], (size_t)nnz))) break;
-    if (P >= 2 && ((rc = dalloc(h, &kbuf[1], (size_t)nnz)) || (rc = dalloc(h, &ut, (size_t)nnz)))) break;
-    if (P >= 2 && h->u.val && (rc = dalloc(h, &vt, (size_t)nnz))) break;
+    // one allocation for every temporary of the sort (mapping ~100 GB piecewise was most of
+    // whole C5's upload time): [counts | keys A | keys B | users | ratings], 256-byte aligned parts
+    {
+      auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+      const size_t b_counts = up((size_t)ntiles * RADIX_DIGITS * 8), b_k = up((size_t)nnz * 4);
+      const size_t b_k1 = P >= 2 ? b_k : 0, b_ut = P >= 2 ? b_k : 0, b_vt = (P >= 2 && h->u.val) ? up((size_t)nnz) : 0;
+      if ((rc = dalloc(h, &pool, b_counts + b_k + b_k1 + b_ut + b_vt))) break;
+      char *q = (char *)pool;
+      counts = (uint64_t *)q; q += b_counts;
+      kbuf[0] = (uint32_t *)q; q += b_k;
+      if (b_k1) { kbuf[1] = (uint32_t *)q; q += b_k1; }
+      if (b_ut) { ut = (uint32_t *)q; q += b_ut; }
+      if (b_vt) { vt = (uint8_t *)q; q += b_vt; }
+    }
     for (uint32_t p = 0; p < P && !rc; ++p) {
       RadixArgs a;
       a.keys_in = p == 0 ? h->u.idx : kbuf[(p - 1) & 1];
@@ -772,7 +782,7 @@ int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
     if ((rc = check_launch(h, "colptr_from_sorted_kernel"))) break;
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "CSC build failed on the device"; rc = HPF_ERR_HIP; }
   } while (0);
-  dfree(bad); dfree(kbuf[0]); dfree(kbuf[1]); dfree(ut); dfree(vt); dfree(counts);
+  dfree(bad); dfree(pool);
   return rc;
 }
 
