@@ -227,6 +227,34 @@ def test_checkpoint_and_resume(tmp_path):
     assert r.returncode != 0
 
 
+def test_checkpoint_and_resume_two_ranks(tmp_path):
+    """the same with users sharded over two processes (`-ngpus 2 -comm host`, both on GPU
+    0): every rank writes and reloads its own snapshot; the merged output files of the
+    resumed run are the uninterrupted run's, text for text."""
+    n, m, K = 300, 200, 6
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    base = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "3", "-rfreq", "2", "-hier",
+            "-ngpus", "2", "-device", "0", "-comm", "host"]
+    a, b = tmp_path / "straight", tmp_path / "resumed"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "10"], cwd=a, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "4", "-checkpoint", "4"], cwd=b, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outb = [p for p in b.iterdir() if p.is_dir()][0]
+    assert (outb / "checkpoint.r0of2.bin").exists() and (outb / "checkpoint.r1of2.bin").exists()
+    r = subprocess.run([str(EXE)] + base + ["-max-iterations", "10", "-resume"], cwd=b, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outa = [p for p in a.iterdir() if p.is_dir()][0]
+    sa, sb = series(outa / "validation.txt"), series(outb / "validation.txt")
+    assert [(x[0], x[1], x[2]) for x in sa] == [(x[0], x[1], x[2]) for x in sb]
+    for nm in ("htheta", "hbeta", "thetarate", "betarate"):
+        for suf in ("", "_shape", "_rate"):
+            assert (outa / f"{nm}{suf}.tsv").read_text() == (outb / f"{nm}{suf}.tsv").read_text(), nm + suf
+    assert (outa / "precision.txt").read_text() == (outb / "precision.txt").read_text()
+
+
 def test_dataset_cache_runs_are_identical(tmp_path):
     """-cache (extension): first run parses the TSVs and writes the binary image,
     the second loads it; every output file must be byte-identical (same CSR,
