@@ -509,17 +509,22 @@ static void gp_initialize_exp(gp *g, orc_rng *r)
   gp_set_to_prior(g);
 }
 
-/* sum_rows gpbase.hh:264-271 */
+/* matrix.hh:327-335  D1Array<T>::sum -- plain left-to-right sum from 0.0 (stride: elements apart) */
+double orc_sum_strided(const double *d, uint32_t n, size_t stride)
+{
+  double s = .0;
+  for (uint32_t i = 0; i < n; ++i) s += d[(size_t)i * stride];
+  return s;
+}
+/* sum_rows gpbase.hh:264-271: v[k] += E[i][k] for i = 0..n-1, into a fresh zeroed Array */
 static void gp_sum_rows(const gp *g, double *v)
 {
-  for (uint32_t i = 0; i < g->n; ++i)
-    for (uint32_t k = 0; k < g->k; ++k) v[k] += g->Ev[(size_t)i * g->k + k];
+  for (uint32_t k = 0; k < g->k; ++k) v[k] += orc_sum_strided(g->Ev + k, g->n, g->k);
 }
-/* sum_cols gpbase.hh:273-280 */
+/* sum_cols gpbase.hh:273-280: v[i] += E[i][k] for k = 0..K-1 */
 static void gp_sum_cols(const gp *g, double *v)
 {
-  for (uint32_t i = 0; i < g->n; ++i)
-    for (uint32_t k = 0; k < g->k; ++k) v[i] += g->Ev[(size_t)i * g->k + k];
+  for (uint32_t i = 0; i < g->n; ++i) v[i] += orc_sum_strided(g->Ev + (size_t)i * g->k, g->k, 1);
 }
 
 /* ------------------------------------------------------------------ */

@@ -43,6 +43,8 @@ double orc_psi(double x);
 
 /* matrix.hh:367-389,399-406 : sequential log-add-exp softmax, in place */
 double orc_logsum(const double *x, uint32_t n);
+/* D1Array<T>::sum (matrix.hh:327-335): the left-to-right sum the row / column sums are made of */
+double orc_sum_strided(const double *d, uint32_t n, size_t stride);
 void   orc_lognormalize(double *x, uint32_t n);
 
 /* ---- ratings store (ratings.cc:63-119) ---- */

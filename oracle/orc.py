@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
     L.orc_psi.restype = C.c_double
     L.orc_logsum.argtypes = [dp, C.c_uint32]
     L.orc_logsum.restype = C.c_double
+    L.orc_sum_strided.argtypes = [dp, C.c_uint32, C.c_size_t]
+    L.orc_sum_strided.restype = C.c_double
     L.orc_lognormalize.argtypes = [dp, C.c_uint32]
     L.orc_ratings_new.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.orc_ratings_new.restype = vp
@@ -143,6 +145,11 @@ def lognormalize(x):
     a = np.array(x, dtype=np.float64)
     lib().orc_lognormalize(a.ctypes.data_as(C.POINTER(C.c_double)), a.size)
     return a
+
+
+def seq_sum(x, stride=1):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    return lib().orc_sum_strided(a.ctypes.data_as(C.POINTER(C.c_double)), a.size // stride, stride)
 
 
 def logsum(x):

@@ -19,7 +19,11 @@
 //       out: f64 M[rows*K]   (M starts at 0.3; add_slice of each phi)
 //   refpart save <in.bin> <matrix.tsv> <vector.tsv>
 //       in : u32 rows, u32 cols, u32 nids, u32 ids[nids], f64 a[rows*cols], f64 v[rows]
-//   refpart env <cli flags as for hgaprec>      (runs Env::Env in the cwd)
+//   refpart env <cli flags as for hgaprec>      (runs Env::Env in the cwd; also prints file_str("/x.tsv"))
+//   refpart arrays <in.bin> <out.bin>
+//       in : u32 n, u32 maxn, f64 fill, f64 x[n]
+//       out: f64 D1Array::sum(), f64 D1Array::sum(maxn), then a D2Array(3, n) after
+//            set_elements(fill) (3n f64), then x after zero() (n f64)
 #include <map>
 #include <stdint.h>
 #include <stdio.h>
@@ -74,6 +78,24 @@ static int cmd_accumulate(const char *in, const char *out) {
   return 0;
 }
 
+static int cmd_arrays(const char *in, const char *out) {
+  FILE *f = fopen(in, "rb"), *g = fopen(out, "wb");
+  uint32_t n, maxn; double fill;
+  rd(f, &n, 4); rd(f, &maxn, 4); rd(f, &fill, 8);
+  Array x(n);
+  rd(f, x.data(), 8 * (size_t)n);
+  double s0 = x.sum(), s1 = x.sum(maxn);
+  fwrite(&s0, 8, 1, g); fwrite(&s1, 8, 1, g);
+  D2Array<double> M(3, n);
+  M.set_elements(fill);
+  const double **d = M.const_data();
+  for (uint32_t i = 0; i < 3; ++i) fwrite(d[i], 8, n, g);
+  x.zero();
+  fwrite(x.data(), 8, n, g);
+  fclose(f); fclose(g);
+  return 0;
+}
+
 static int cmd_save(const char *in, const char *mt, const char *vt) {
   FILE *f = fopen(in, "rb");
   uint32_t rows, cols, nids;
@@ -122,6 +144,7 @@ static int cmd_env(int argc, char **argv) {
           true, binary, bias, hier, false, true, false, false, false, false,
           false, rating_threshold, false, false, 0.1, 10,
           false, false, false, false, false, false, false);
+  printf("%s\n", Env::file_str("/x.tsv").c_str());
   printf("%s\n", Env::prefix.c_str());
   return 0;
 }
@@ -129,8 +152,9 @@ static int cmd_env(int argc, char **argv) {
 int main(int argc, char **argv) {
   if (argc >= 4 && !strcmp(argv[1], "softmax")) return cmd_softmax(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "accumulate")) return cmd_accumulate(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "arrays")) return cmd_arrays(argv[2], argv[3]);
   if (argc >= 5 && !strcmp(argv[1], "save")) return cmd_save(argv[2], argv[3], argv[4]);
   if (argc >= 2 && !strcmp(argv[1], "env")) return cmd_env(argc - 2, argv + 2);
-  fprintf(stderr, "usage: refpart softmax|accumulate|save|env ...\n");
+  fprintf(stderr, "usage: refpart softmax|accumulate|arrays|save|env ...\n");
   return 2;
 }

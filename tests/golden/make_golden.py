@@ -87,6 +87,28 @@ def accumulate_cases():
                       "first K entries of a K+2 wide phi; rows start at the 0.3 prior", "cases": cases}
 
 
+def arrays_cases():
+    """D1Array::sum (a plain left-to-right double sum -- what sum_rows / sum_cols of gpbase.hh
+    are made of), D2Array::set_elements, D1Array::zero"""
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1, 2, 7, 100, 1000):
+        x = rng.gamma(0.3, 1.0, size=n) * 10.0 ** rng.integers(-8, 6, size=n)
+        maxn, fill = max(1, n // 2), 0.3
+        with tempfile.TemporaryDirectory() as td:
+            fin, fout = Path(td) / "in.bin", Path(td) / "out.bin"
+            with open(fin, "wb") as f:
+                f.write(struct.pack("<IId", n, maxn, fill))
+                f.write(np.asarray(x, "<f8").tobytes())
+            subprocess.run([str(REFPART), "arrays", str(fin), str(fout)], check=True)
+            raw = np.fromfile(fout, "<f8")
+        cases.append({"x": hexl(x), "maxn": maxn, "fill": float(fill).hex(), "sum": float(raw[0]).hex(),
+                      "sum_maxn": float(raw[1]).hex(), "set_elements": hexl(raw[2:2 + 3 * n]),
+                      "zero": hexl(raw[2 + 3 * n:2 + 4 * n])})
+    return {"source": "D1Array<double>::sum matrix.hh:327-335, zero 200-203, D2Array<double>::set_elements 930-936",
+            "cases": cases}
+
+
 def save_cases():
     rng = np.random.default_rng(3)
     cases = []
@@ -128,9 +150,10 @@ def env_cases():
         with tempfile.TemporaryDirectory() as td:
             r = subprocess.run([str(REFPART), "env"] + args, cwd=td, check=True, capture_output=True, text=True)
             prefix = r.stdout.strip().splitlines()[-1]
+            file_str = r.stdout.strip().splitlines()[-2]
             param = (Path(td) / prefix / "param.txt").read_text()
             files = sorted(os.listdir(Path(td) / prefix))
-        cases.append({"args": args, "prefix": prefix, "param_txt": param, "files": files})
+        cases.append({"args": args, "prefix": prefix, "file_str_x_tsv": file_str, "param_txt": param, "files": files})
     return {"source": "Env::Env /root/reference/src/env.hh:216-408 (directory name, param.txt head), "
                       "Logger::initialize log.cc:9-118", "cases": cases}
 
@@ -139,7 +162,7 @@ def main():
     if not REFPART.exists():
         sys.exit("oracle/_ref/refpart missing: run `make -C oracle ref` where /root/reference exists")
     GOLD.mkdir(parents=True, exist_ok=True)
-    for name, fn in (("softmax", softmax_cases), ("accumulate", accumulate_cases),
+    for name, fn in (("softmax", softmax_cases), ("accumulate", accumulate_cases), ("arrays", arrays_cases),
                      ("save", save_cases), ("env", env_cases)):
         (GOLD / f"{name}.json").write_text(json.dumps(fn(), indent=1))
         print("wrote", GOLD / f"{name}.json")

@@ -31,6 +31,13 @@ def test_prefix_matches_reference_env():
         assert hostlib.prefix(c["args"]) == c["prefix"], c["args"]
 
 
+def test_file_str_matches_reference_env():
+    # Env::file_str (env.hh:209-214): every output path is prefix + name
+    d = json.loads((GOLD / "env.json").read_text())
+    for c in d["cases"]:
+        assert hostlib.prefix(c["args"]) + "/x.tsv" == c["file_str_x_tsv"], c["args"]
+
+
 def test_param_txt_head_matches_reference_env(tmp_path):
     d = json.loads((GOLD / "env.json").read_text())
     cwd = os.getcwd()

@@ -163,3 +163,18 @@ def test_initialize_values_follow_the_stream(orc):
     assert np.array_equal(M.state("BETA_E"), beta_shape / brate)
     assert np.allclose(M.state("BETA_ELOG"), orc.psi(beta_shape.ravel()).reshape(m, K) - np.log(brate),
                        rtol=0, atol=1e-15)
+
+
+def test_sum_set_elements_zero_golden_bit_exact(orc):
+    """D1Array::sum is a plain left-to-right sum from 0.0 -- what GPMatrix::sum_rows / sum_cols
+    (gpbase.hh:264-280) are made of; the oracle's row / column sums go through the same loop
+    (also with a stride, as sum_rows walks a column).  set_elements / zero carry no arithmetic."""
+    d = json.loads((GOLD / "arrays.json").read_text())
+    for c in d["cases"]:
+        x = unhex(c["x"])
+        assert orc.seq_sum(x) == float.fromhex(c["sum"])
+        assert orc.seq_sum(x[: c["maxn"]]) == float.fromhex(c["sum_maxn"])
+        wide = np.zeros((x.size, 3)); wide[:, 0] = x               # the same numbers, 3 apart
+        assert orc.seq_sum(wide.ravel(), stride=3) == float.fromhex(c["sum"])
+        assert np.all(unhex(c["set_elements"]) == float.fromhex(c["fill"])) and len(c["set_elements"]) == 3 * x.size
+        assert np.all(unhex(c["zero"]) == 0.0)
