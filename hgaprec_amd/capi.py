@@ -235,8 +235,12 @@ class Hpf:
             self._h, C.c_void_p(rowptr.data_ptr()), C.c_void_p(col.data_ptr() if col.numel() else None),
             C.c_void_p(val.data_ptr()) if val is not None and val.numel() else None))
 
-    def get_csc(self, nnz: int, with_vals=True):
+    def get_csc(self, nnz: int | None = None, with_vals=True):
         """host copies of the item-major view: colptr[m+1], users[nnz], vals[nnz] | None"""
+        have = self.work_info()["nnz"]
+        if nnz is not None and int(nnz) != have:
+            raise ValueError(f"the uploaded matrix has {have} nonzeros, not {nnz}")
+        nnz = have
         colptr = np.empty(self.n_items + 1, np.int64)
         users = np.empty(nnz, np.uint32)
         vals = np.empty(nnz, np.uint8) if with_vals else None
