@@ -66,6 +66,10 @@ def main():
         if "TCC_HIT_sum" in cs and "TCC_MISS_sum" in cs:
             h_, m_ = cs["TCC_HIT_sum"][0], cs["TCC_MISS_sum"][0]
             row["L2_hit_rate"] = round(h_ / max(h_ + m_, 1.0), 4)
+        if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"][0] > 0:
+            row["wait_any_share"] = round(cs["SQ_WAIT_ANY"][0] / cs["SQ_WAVE_CYCLES"][0], 3)      # waves parked on s_waitcnt
+            if "SQ_ACTIVE_INST_ANY" in cs:
+                row["issuing_share"] = round(cs["SQ_ACTIVE_INST_ANY"][0] / cs["SQ_WAVE_CYCLES"][0], 3)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # KiB counters; FETCH_SIZE counts 64 B per 128-B request on gfx950 => x2 (MI355X_MICROARCH.md, HBM)
             row["hbm_side_bytes"] = int((2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024)
