@@ -516,10 +516,14 @@ double orc_sum_strided(const double *d, uint32_t n, size_t stride)
   for (uint32_t i = 0; i < n; ++i) s += d[(size_t)i * stride];
   return s;
 }
-/* sum_rows gpbase.hh:264-271: v[k] += E[i][k] for i = 0..n-1, into a fresh zeroed Array */
+/* sum_rows gpbase.hh:264-271: v[k] += E[i][k] for i = 0..n-1, into a fresh zeroed Array.
+ * Per column this is orc_sum_strided(Ev + k, n, K) -- the same additions in the same order
+ * (tests/test_oracle_pins.py checks the two against each other); rows stay the outer loop,
+ * as in the reference, so that the timed CPU baseline streams the matrix once */
 static void gp_sum_rows(const gp *g, double *v)
 {
-  for (uint32_t k = 0; k < g->k; ++k) v[k] += orc_sum_strided(g->Ev + k, g->n, g->k);
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) v[k] += g->Ev[(size_t)i * g->k + k];
 }
 /* sum_cols gpbase.hh:273-280: v[i] += E[i][k] for k = 0..K-1 */
 static void gp_sum_cols(const gp *g, double *v)

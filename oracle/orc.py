@@ -147,9 +147,11 @@ def lognormalize(x):
     return a
 
 
-def seq_sum(x, stride=1):
+def seq_sum(x, stride=1, n=None):
     a = np.ascontiguousarray(x, dtype=np.float64)
-    return lib().orc_sum_strided(a.ctypes.data_as(C.POINTER(C.c_double)), a.size // stride, stride)
+    n = a.size // stride if n is None else int(n)
+    assert (n - 1) * stride < a.size or n == 0
+    return lib().orc_sum_strided(a.ctypes.data_as(C.POINTER(C.c_double)), n, stride)
 
 
 def logsum(x):

@@ -178,3 +178,20 @@ def test_sum_set_elements_zero_golden_bit_exact(orc):
         assert orc.seq_sum(wide.ravel(), stride=3) == float.fromhex(c["sum"])
         assert np.all(unhex(c["set_elements"]) == float.fromhex(c["fill"])) and len(c["set_elements"]) == 3 * x.size
         assert np.all(unhex(c["zero"]) == 0.0)
+
+
+def test_model_rate_sums_are_the_pinned_loop(orc):
+    """the column sums inside the oracle's sweep (sum_rows, gpbase.hh:264-271) are, per column,
+    the left-to-right loop pinned above: without -hier the theta rate after one iteration is
+    0.3 + sum_i E[beta_ik] (gpbase.hh:558-562), bit for bit"""
+    from tests.util import make_problem
+    n, m, K = 40, 30, 7
+    rowptr, col, val = make_problem(n, m, 300, 3)
+    M = orc.Model(n, m, K, False, False, False)
+    M.set_csr(rowptr, col, val)
+    M.initialize(11)
+    be = M.state("BETA_E").copy()
+    M.iterate(1)
+    tr = M.state("THETA_RATE")
+    for k in range(K):
+        assert tr[k] == 0.3 + orc.seq_sum(be.ravel()[k:], stride=K, n=m)
