@@ -3,7 +3,8 @@
 // CSR -> (CSR, CSC, segment lists), the per-iteration launch sequence, the
 // exchange buffer for the multi-GPU all-reduce, hipEvent timing.
 //
-// Device layout (all fp64, row stride ld = round_up(K + 2*bias, 2)):
+// Device layout (all fp64; row stride ld = G*R*V of the phi kernel shape >= K + 2*bias,
+// the columns beyond the live ones hold zeros):
 //   user side  theta: S,E,L,W [n x ld]   column K   = user bias (thetabias)
 //                                         column K+1 = 0 ("junk": Elog 0)
 //   item side  beta : S,E,L,W [m x ld]   column K   = junk, column K+1 = item bias
@@ -40,22 +41,18 @@ struct Side {
   double *rate_set = nullptr;     // rate handed in by hpf_set_state (export before iter 0)
   size_t  rate_set_count = 0;
   double *prior_shape_set = nullptr, *prior_elog_set = nullptr;  // xi/eta extras
-  // phi pass work lists.  phases == 2: the nonzeros of every row are
-  // partitioned into those whose other-side row belongs to the "hot" set (the
-  // highest-degree rows whose W fits one XCD's 4 MiB L2) and the rest; phase 0
-  // walks the hot parts (gathers hit L2), phase 1 adds the cold parts.
-  uint32_t phases = 1;
-  Seg *segs[2] = {nullptr, nullptr}; uint32_t nseg[2] = {0, 0};
-  LongRow *longrows[2] = {nullptr, nullptr}; uint32_t nlong[2] = {0, 0};
+  // phi pass work list: segments of <= seg_max nonzeros of one row; rows of several
+  // segments ("long") have their segment sums combined by a second kernel
+  Seg *segs = nullptr; uint32_t nseg = 0;
+  LongRow *longrows = nullptr; uint32_t nlong = 0;
   double *partial = nullptr; uint32_t npartial = 0;
   // rows with more than HUGE_SLOTS segments are combined in two levels so that
   // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
   // consecutive partials are summed into partial2 (grouprows), then the group
   // sums into S (hugerows, reading partial2)
-  LongRow *grouprows[2] = {nullptr, nullptr}; uint32_t ngroup[2] = {0, 0};
-  LongRow *hugerows[2] = {nullptr, nullptr}; uint32_t nhuge[2] = {0, 0};
+  LongRow *grouprows = nullptr; uint32_t ngroup = 0;
+  LongRow *hugerows = nullptr; uint32_t nhuge = 0;
   double *partial2 = nullptr; uint32_t npartial2 = 0;
-  double hot_share = 0.0; uint32_t hot_rows = 0;
   uint32_t *idx = nullptr; uint8_t *val = nullptr;
   int32_t bias_col = -1, junk_col = -1;
   double bias_rate_add = 0.0;
@@ -95,10 +92,6 @@ struct hpf_handle {
   uint32_t sweep_blocks_max = 2048;     // 8 waves per SIMD (HPF_SWEEP_BLOCKS); 1024 -> 2048: C2 user sweep 0.587 -> 0.544 ms
   uint32_t seg_max = 512;
   uint32_t huge_slots = 256, group_slots = 64;  // two-level combine above huge_slots segments (HPF_HUGE_SLOTS)
-  bool hot_force = false;               // HPF_HOT_FORCE=1: split even when the estimate says no (tests)
-  uint64_t hot_bytes = 0;               // HPF_HOT_BYTES: size of the L2-resident hot set; 0 = single phase.
-                                        // Measured at C2 (3.5 MiB hot set): user pass 4.3 -> 5.7 ms -- the
-                                        // short hot/cold segments cost more than the L2 hits save; kept as a knob.
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
@@ -195,8 +188,7 @@ void free_side(Side &s, bool S_external)
   dfree(s.prior_elog); dfree(s.prior_elog_used);
   dfree(s.colsum_used); dfree(s.colsum_part);
   dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
-  dfree(s.segs[0]); dfree(s.segs[1]); dfree(s.longrows[0]); dfree(s.longrows[1]);
-  dfree(s.grouprows[0]); dfree(s.grouprows[1]); dfree(s.hugerows[0]); dfree(s.hugerows[1]);
+  dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
   dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
   s = Side();
 }
@@ -510,137 +502,6 @@ int copy_out_dev(hpf_handle *h, const double *dev, uint32_t ld, uint32_t col0, d
   return HPF_OK;
 }
 
-// ---- work lists -----------------------------------------------------------
-// segments of at most seg_max nonzeros for the row parts [start[r], start[r]+len[r]);
-// skip_empty: rows with len 0 get no segment (cold phase), else one empty segment
-void build_segments(const std::vector<int64_t> &start, const std::vector<uint32_t> &len,
-                    uint32_t seg_max, bool skip_empty, uint32_t *slot_io,
-                    std::vector<Seg> &segs, std::vector<LongRow> &longs)
-{
-  segs.clear(); longs.clear();
-  uint32_t slot = *slot_io;
-  const uint32_t rows = (uint32_t)len.size();
-  for (uint32_t r = 0; r < rows; ++r) {
-    const uint64_t deg = len[r];
-    if (deg == 0 && skip_empty) continue;
-    if (deg <= seg_max) {
-      Seg s; s.start = start[r]; s.row = r; s.len = (uint32_t)deg; s.pslot = -1; s.pad = 0;
-      segs.push_back(s);
-    } else {
-      const uint32_t ns = (uint32_t)((deg + seg_max - 1) / seg_max);
-      LongRow lr; lr.row = r; lr.first_slot = slot; lr.nslots = ns; lr.pad = 0;
-      longs.push_back(lr);
-      for (uint32_t k = 0; k < ns; ++k) {
-        Seg s; s.start = start[r] + (int64_t)k * seg_max; s.row = r;
-        s.len = (uint32_t)std::min<uint64_t>(seg_max, deg - (uint64_t)k * seg_max);
-        s.pslot = (int32_t)slot++; s.pad = 0;
-        segs.push_back(s);
-      }
-    }
-  }
-  *slot_io = slot;
-}
-
-// Work lists of one side.  s.idx / s.val already hold the side's nonzeros in HBM
-// (row-major for `ptr`); ptr / ptr_oth are HOST copies of this side's and the
-// other side's row pointers.  Only the experimental hot/cold split (HPF_HOT_BYTES)
-// touches the nonzeros again: it reorders them inside each row on the host.
-int upload_side_work(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows, uint64_t nnz,
-                     const int64_t *ptr_oth, uint32_t rows_oth)
-{
-  for (int p = 0; p < 2; ++p) {
-    dfree(s.segs[p]); dfree(s.longrows[p]); dfree(s.grouprows[p]); dfree(s.hugerows[p]);
-    s.segs[p] = nullptr; s.longrows[p] = s.grouprows[p] = s.hugerows[p] = nullptr;
-    s.nseg[p] = s.nlong[p] = s.ngroup[p] = s.nhuge[p] = 0;
-  }
-  dfree(s.partial); dfree(s.partial2);
-  s.partial = nullptr; s.partial2 = nullptr;
-  s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0;
-  int rc;
-
-  // ---- hot set: the highest-degree other-side rows whose W rows fit in one L2
-  const uint64_t row_bytes = (uint64_t)h->ld * 8;
-  const uint32_t H = (uint32_t)std::min<uint64_t>(h->hot_bytes / row_bytes, rows_oth);
-  std::vector<uint8_t> hot;
-  if (H > 0 && H < rows_oth && nnz > 0) {
-    std::vector<uint32_t> order(rows_oth);
-    for (uint32_t r = 0; r < rows_oth; ++r) order[r] = r;
-    std::nth_element(order.begin(), order.begin() + H, order.end(), [&](uint32_t x, uint32_t y) {
-      const int64_t dx = ptr_oth[x + 1] - ptr_oth[x], dy = ptr_oth[y + 1] - ptr_oth[y];
-      return dx != dy ? dx > dy : x < y; });
-    uint64_t hot_nnz = 0;
-    for (uint32_t k = 0; k < H; ++k) hot_nnz += (uint64_t)(ptr_oth[order[k] + 1] - ptr_oth[order[k]]);
-    // worth it when the gathers that become L2 hits outweigh (2x) the extra
-    // read-modify-write of the owner rows in the second phase
-    const double gain = (double)hot_nnz * (double)row_bytes, cost = 2.0 * (double)rows * (double)row_bytes * 2.0;
-    if (gain > cost || h->hot_force) {
-      hot.assign(rows_oth, 0);
-      for (uint32_t k = 0; k < H; ++k) hot[order[k]] = 1;
-      s.phases = 2; s.hot_share = (double)hot_nnz / (double)nnz; s.hot_rows = H;
-    }
-  }
-
-  // ---- (re)order the nonzeros of each row: hot ones first, stable
-  std::vector<int64_t> start0(rows), start1(rows);
-  std::vector<uint32_t> len0(rows), len1(rows, 0);
-  if (s.phases == 2) {
-    std::vector<uint32_t> idx(nnz), ridx(nnz); std::vector<uint8_t> val, rval;
-    if ((rc = d2h(h, idx.data(), s.idx, nnz * 4))) return rc;
-    if (s.val) { val.resize(nnz); rval.resize(nnz); if ((rc = d2h(h, val.data(), s.val, nnz))) return rc; }
-    for (uint32_t r = 0; r < rows; ++r) {
-      const int64_t a = ptr[r], b = ptr[r + 1];
-      int64_t w = a;
-      for (int64_t j = a; j < b; ++j) if (hot[idx[j]]) { ridx[w] = idx[j]; if (s.val) rval[w] = val[j]; ++w; }
-      start0[r] = a; len0[r] = (uint32_t)(w - a); start1[r] = w; len1[r] = (uint32_t)(b - w);
-      for (int64_t j = a; j < b; ++j) if (!hot[idx[j]]) { ridx[w] = idx[j]; if (s.val) rval[w] = val[j]; ++w; }
-    }
-    if ((rc = h2d(h, s.idx, ridx.data(), nnz * 4))) return rc;
-    if (s.val && (rc = h2d(h, s.val, rval.data(), nnz))) return rc;
-  } else {
-    for (uint32_t r = 0; r < rows; ++r) { start0[r] = ptr[r]; len0[r] = (uint32_t)(ptr[r + 1] - ptr[r]); }
-  }
-
-  std::vector<Seg> segs[2]; std::vector<LongRow> longs[2]; uint32_t np = 0;
-  build_segments(start0, len0, h->seg_max, false, &np, segs[0], longs[0]);
-  if (s.phases == 2) build_segments(start1, len1, h->seg_max, true, &np, segs[1], longs[1]);
-  s.npartial = np;
-  // split off the very long rows (two-level combine)
-  std::vector<LongRow> groups[2], huge[2]; uint32_t np2 = 0;
-  for (int p = 0; p < 2; ++p) {
-    std::vector<LongRow> keep;
-    for (const LongRow &lr : longs[p]) {
-      if (lr.nslots <= h->huge_slots) { keep.push_back(lr); continue; }
-      LongRow top; top.row = lr.row; top.first_slot = np2; top.nslots = 0; top.pad = 0;
-      for (uint32_t q = 0; q < lr.nslots; q += h->group_slots) {
-        LongRow g; g.row = np2++; g.first_slot = lr.first_slot + q;
-        g.nslots = std::min<uint32_t>(h->group_slots, lr.nslots - q); g.pad = 0;
-        groups[p].push_back(g); top.nslots++;
-      }
-      huge[p].push_back(top);
-    }
-    longs[p].swap(keep);
-  }
-  s.npartial2 = np2;
-  for (int p = 0; p < 2; ++p) {
-    s.ngroup[p] = (uint32_t)groups[p].size(); s.nhuge[p] = (uint32_t)huge[p].size();
-    if (s.ngroup[p]) {
-      if ((rc = dalloc(h, &s.grouprows[p], groups[p].size()))) return rc;
-      if ((rc = dalloc(h, &s.hugerows[p], huge[p].size()))) return rc;
-      if ((rc = h2d(h, s.grouprows[p], groups[p].data(), groups[p].size() * sizeof(LongRow)))) return rc;
-      if ((rc = h2d(h, s.hugerows[p], huge[p].data(), huge[p].size() * sizeof(LongRow)))) return rc;
-    }
-    s.nseg[p] = (uint32_t)segs[p].size(); s.nlong[p] = (uint32_t)longs[p].size();
-    if ((rc = dalloc(h, &s.segs[p], segs[p].size()))) return rc;
-    if ((rc = dalloc(h, &s.longrows[p], longs[p].size()))) return rc;
-    if ((rc = h2d(h, s.segs[p], segs[p].data(), segs[p].size() * sizeof(Seg)))) return rc;
-    if ((rc = h2d(h, s.longrows[p], longs[p].data(), longs[p].size() * sizeof(LongRow)))) return rc;
-  }
-  if ((rc = dalloc(h, &s.partial, (size_t)np * h->ld))) return rc;
-  if (np2 && (rc = dalloc(h, &s.partial2, (size_t)np2 * h->ld))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return HPF_OK;
-}
-
 // exclusive scan of n counters (uint32 or uint64) into uint64 out[0..n) (+ out[n] = total)
 template <typename IN>
 int device_scan(hpf_handle *h, const IN *in, uint64_t n, uint64_t *out, bool write_total)
@@ -664,18 +525,15 @@ int device_scan(hpf_handle *h, const IN *in, uint64_t n, uint64_t *out, bool wri
 }
 
 // Work lists of one side cut on the device from its row pointers (dptr, in HBM): nothing of
-// size O(rows) or O(nnz) crosses PCIe.  Same lists, in the same order, as the host loop of
-// upload_side_work (which stays for the hot/cold experiment that reorders nonzeros).
+// size O(rows) or O(nnz) crosses PCIe.
 int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
 {
-  for (int p = 0; p < 2; ++p) {
-    dfree(s.segs[p]); dfree(s.longrows[p]); dfree(s.grouprows[p]); dfree(s.hugerows[p]);
-    s.segs[p] = nullptr; s.longrows[p] = s.grouprows[p] = s.hugerows[p] = nullptr;
-    s.nseg[p] = s.nlong[p] = s.ngroup[p] = s.nhuge[p] = 0;
-  }
+  dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
+  s.segs = nullptr; s.longrows = s.grouprows = s.hugerows = nullptr;
+  s.nseg = s.nlong = s.ngroup = s.nhuge = 0;
   dfree(s.partial); dfree(s.partial2);
   s.partial = nullptr; s.partial2 = nullptr;
-  s.phases = 1; s.hot_share = 0.0; s.hot_rows = 0; s.npartial = 0; s.npartial2 = 0;
+  s.npartial = 0; s.npartial2 = 0;
   if (rows == 0) return HPF_OK;
   int rc = HPF_OK;
   uint64_t *cnt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -698,13 +556,12 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
     if (e != hipSuccess) { h->err = std::string("seg_plan_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
     if (hb) { h->err = "row pointers must start at 0 and be monotone"; rc = HPF_ERR_INVALID; break; }
     if (tot[0] > 0xffffffffull || tot[1] > 0x7fffffffull) { h->err = "too many segments for 32-bit work lists"; rc = HPF_ERR_UNSUPPORTED; break; }
-    s.nseg[0] = (uint32_t)tot[0]; s.npartial = (uint32_t)tot[1]; s.nlong[0] = (uint32_t)tot[2];
-    s.nhuge[0] = (uint32_t)tot[3]; s.ngroup[0] = s.npartial2 = (uint32_t)tot[4];
-    if ((rc = dalloc(h, &s.segs[0], s.nseg[0])) || (rc = dalloc(h, &s.longrows[0], s.nlong[0]))) break;
-    if (s.ngroup[0] && ((rc = dalloc(h, &s.grouprows[0], s.ngroup[0])) || (rc = dalloc(h, &s.hugerows[0], s.nhuge[0])))) break;
-    if ((rc = dalloc(h, &s.segs[1], 0)) || (rc = dalloc(h, &s.longrows[1], 0))) break;
+    s.nseg = (uint32_t)tot[0]; s.npartial = (uint32_t)tot[1]; s.nlong = (uint32_t)tot[2];
+    s.nhuge = (uint32_t)tot[3]; s.ngroup = s.npartial2 = (uint32_t)tot[4];
+    if ((rc = dalloc(h, &s.segs, s.nseg)) || (rc = dalloc(h, &s.longrows, s.nlong))) break;
+    if (s.ngroup && ((rc = dalloc(h, &s.grouprows, s.ngroup)) || (rc = dalloc(h, &s.hugerows, s.nhuge)))) break;
     hipLaunchKernelGGL(seg_fill_kernel, dim3(grid_for(rows)), dim3(256), 0, h->stream, dptr, rows, h->seg_max,
-                       h->huge_slots, h->group_slots, pl, s.segs[0], s.longrows[0], s.hugerows[0], s.grouprows[0]);
+                       h->huge_slots, h->group_slots, pl, s.segs, s.longrows, s.hugerows, s.grouprows);
     if ((rc = check_launch(h, "seg_fill_kernel"))) break;
     if ((rc = dalloc(h, &s.partial, (size_t)s.npartial * h->ld))) break;
     if (s.npartial2 && (rc = dalloc(h, &s.partial2, (size_t)s.npartial2 * h->ld))) break;
@@ -865,34 +722,31 @@ int prepare_derived(hpf_handle *h)
 int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
   const int side = &own == &h->it ? 1 : 0;
-  for (uint32_t ph = 0; ph < own.phases; ++ph) {
-    PhiArgs a;
-    a.segs = own.segs[ph]; a.nseg = own.nseg[ph]; a.idx = own.idx; a.val = own.val;
-    a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.ld = h->ld;
-    a.accumulate = ph; a.flags = h->flags;
-    if (a.nseg) {
-      const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-      if (!launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream)) {
-        h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
-      }
+  PhiArgs a;
+  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
+  a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
+  if (a.nseg) {
+    const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+    if (!launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream)) {
+      h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
     }
-    // the event separates the (last) phi kernel from the combine that follows it
-    if (ph + 1 == own.phases && !h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
-    if (own.ngroup[ph]) {                       // level 1 of the very long rows: partial -> partial2
-      const uint32_t blocks = std::min<uint32_t>((own.ngroup[ph] + 3) / 4, 16384);
-      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                         own.grouprows[ph], own.ngroup[ph], own.partial, own.partial2, h->ld, 0u);
-    }
-    if (own.nlong[ph]) {
-      const uint32_t blocks = std::min<uint32_t>((own.nlong[ph] + 3) / 4, 16384);
-      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                         own.longrows[ph], own.nlong[ph], own.partial, own.S, h->ld, ph);
-    }
-    if (own.nhuge[ph]) {                        // level 2: partial2 -> S
-      const uint32_t blocks = std::min<uint32_t>((own.nhuge[ph] + 3) / 4, 16384);
-      hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                         own.hugerows[ph], own.nhuge[ph], own.partial2, own.S, h->ld, ph);
-    }
+  }
+  // the event separates the phi kernel from the combine that follows it
+  if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
+  if (own.ngroup) {                       // level 1 of the very long rows: partial -> partial2
+    const uint32_t blocks = std::min<uint32_t>((own.ngroup + 3) / 4, 16384);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       own.grouprows, own.ngroup, own.partial, own.partial2, h->ld);
+  }
+  if (own.nlong) {
+    const uint32_t blocks = std::min<uint32_t>((own.nlong + 3) / 4, 16384);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       own.longrows, own.nlong, own.partial, own.S, h->ld);
+  }
+  if (own.nhuge) {                        // level 2: partial2 -> S
+    const uint32_t blocks = std::min<uint32_t>((own.nhuge + 3) / 4, 16384);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       own.hugerows, own.nhuge, own.partial2, own.S, h->ld);
   }
   return check_launch(h, "phi pass");
 }
@@ -904,8 +758,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   SweepArgs a;
   a.S = s.S; a.W = s.W; a.w32 = h->w32;
   s.l_stale = true; s.es_stale = true;
-  a.prior_E = s.prior_E; a.prior_used = s.prior_used; a.prior_rate = s.prior_rate;
-  a.prior_elog = s.prior_elog; a.prior_elog_used = s.prior_elog_used;
+  a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
   a.colsum_oth = colsum_oth; a.colsum_part = s.colsum_part;
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
@@ -914,6 +767,10 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
+  if (h->cfg.hier && s.rows)                // xi / eta: E and Elog from the rate the sweep just wrote
+    hipLaunchKernelGGL(prior_update_kernel, dim3(std::min<uint32_t>((s.rows + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       s.prior_E, s.prior_used, s.prior_rate, s.prior_elog, s.prior_elog_used, s.rows,
+                       h->cfg.s_prior + (double)h->K * h->cfg.s_prior, a.psi_prior_shape);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
                      s.colsum_part, s.sweep_blocks, h->ld, colsum_out);
   return check_launch(h, "row sweep");
@@ -1097,17 +954,14 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
   h->w32 = cfg->w_storage == 1;          // only ever chosen by the caller's hpf_config
-  if (const char *e = getenv("HPF_H2D")) h->xfer_mode = !strcmp(e, "plain") ? 0 : !strcmp(e, "register") ? 2 : 1;
-  if (const char *e = getenv("HPF_H2D_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) h->xfer_threads = (unsigned)v; }
   if (cfg->w_storage > 1) { delete h; return HPF_ERR_INVALID; }
-  // 16-byte rows of W: 2 doubles or 4 floats
-  h->K = cfg->K; h->C = C; h->ld = h->w32 ? (C + 3u) & ~3u : (C + 1u) & ~1u;
-  // HPF_LD_ROUND=r (experiments): round the row stride up to a multiple of r doubles, e.g. 16
-  // makes every row start on a 128-byte line (K=100: 800-byte rows become 896)
-  if (const char *e = getenv("HPF_LD_ROUND")) {
-    const int r = atoi(e);
-    if (r >= 2 && r <= 64 && (r & (r - 1)) == 0 && (!h->w32 || r >= 4)) h->ld = (h->ld + (uint32_t)r - 1) & ~((uint32_t)r - 1);
-  }
+  h->K = cfg->K; h->C = C;
+  // Tuning knobs are read from the environment ONLY under HPF_EXPERIMENTAL=1 (tests, tools/):
+  // a stray variable must not change the layout or the summation order of a production run.
+  const bool experimental = [] { const char *e = getenv("HPF_EXPERIMENTAL"); return e && atoi(e) == 1; }();
+  auto knob = [&](const char *name) -> const char * { return experimental ? getenv(name) : nullptr; };
+  if (const char *e = knob("HPF_H2D")) h->xfer_mode = !strcmp(e, "plain") ? 0 : !strcmp(e, "register") ? 2 : 1;
+  if (const char *e = knob("HPF_H2D_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) h->xfer_threads = (unsigned)v; }
 
   auto fail = [&](int rc) { hpf_destroy(h); return rc; };
   if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -1119,15 +973,18 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     for (int e = 0; e < 8; ++e)
       if (hipEventCreate(&h->evr[r][e]) != hipSuccess) return fail(HPF_ERR_HIP);
 
-  // kernel configuration (HPF_PHI_CFG="G,R,V" / HPF_SEG_MAX / HPF_PHI_BLOCKS override)
+  // Kernel shape and row stride.  The phi pass gives G lanes to a nonzero, each with R loads
+  // of V elements; the row stride of every device matrix is EXACTLY ld = G*R*V elements
+  // (round 3): the live columns K + 2*bias are padded with zero columns, so the kernels carry
+  // no column test (K=100: 800-byte rows become 896 = seven whole 128-byte lines, the
+  // number of lines a gather of an unaligned 800-byte row touched anyway).
   {
     // 16-byte loads when they pad no worse than 8-byte ones (measured: C2
-    // phi_user 4.36 ms vs 4.52 ms; the passes are fabric-bound either way).
-    // Elements per load: doubles 1|2, floats 2|4.
+    // phi_user 4.36 ms vs 4.52 ms).  Elements per load: doubles 1|2, floats 2|4.
     const int Vs = h->w32 ? 2 : 1, Vl = 2 * Vs;
     int g1 = 0, r1 = 0, g2 = 0, r2 = 0;
     long w1 = 1L << 40, w2 = 1L << 40;
-    const bool ok1 = choose_cfg(h->ld, Vs, &g1, &r1, 8, &w1), ok2 = choose_cfg(h->ld, Vl, &g2, &r2, 8, &w2);
+    const bool ok1 = choose_cfg(C, Vs, &g1, &r1, 8, &w1), ok2 = choose_cfg(C, Vl, &g2, &r2, 8, &w2);
     if (!ok1 && !ok2) return fail(HPF_ERR_UNSUPPORTED);
     if (!ok1) w1 = 1L << 40;
     if (!ok2) w2 = 1L << 40;
@@ -1137,30 +994,40 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       // f32 rows are half as long: measured at C2 (K=100) the passes want 256
       // contiguous bytes per nonzero-group -- (G,R,V) = (16,2,4): 3.7 + 3.4 ms
       // against 5.0 + 3.8 ms for (8,4,4) and 9.8 + 5.3 ms for the least-padding (4,7,4)
-      const int g = h->ld > 512 ? 32 : h->ld > 32 ? 16 : h->ld > 16 ? 8 : 4;
-      h->phiG = g; h->phiV = 4; h->phiR = (int)((h->ld + (uint32_t)(4 * g) - 1) / (uint32_t)(4 * g));
+      const int g = C > 512 ? 32 : C > 32 ? 16 : C > 16 ? 8 : 4;
+      h->phiG = g; h->phiV = 4; h->phiR = (int)((C + (uint32_t)(4 * g) - 1) / (uint32_t)(4 * g));
+    }
+    if (const char *e = knob("HPF_PHI_CFG")) {           // "G,R,V"
+      int g = 0, r = 0, v = 0;
+      if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&
+          (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && (uint32_t)(g * r * v) >= C && g * r * v <= 2048) {
+        h->phiG = g; h->phiR = r; h->phiV = v;
+      }
+    }
+    h->ld = (uint32_t)(h->phiG * h->phiR * h->phiV);
+    // the row sweep gives G' lanes to a row with R' columns each, G'*R' == ld exactly
+    h->swG = h->swR = 0;
+    const int Gs[5] = {64, 32, 16, 8, 4};
+    int best = 1 << 30;
+    for (int g : Gs) {
+      if (h->ld % (uint32_t)g) continue;
+      const int r = (int)(h->ld / (uint32_t)g);
+      if (r < 1 || r > (g == 64 ? 16 : 8)) continue;
+      const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (g * 8 < 128 ? 1 : 0);   // same preferences as round 1's K sweep
+      if (p < best || (p == best && g < h->swG)) { best = p; h->swG = g; h->swR = r; }
+    }
+    if (!h->swG) return fail(HPF_ERR_UNSUPPORTED);
+    if (const char *e = knob("HPF_SWEEP_CFG")) {         // "G,R" with G*R == ld
+      int g = 0, r = 0;
+      if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= (g == 64 ? 16 : 8) && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
+          (uint32_t)(g * r) == h->ld) { h->swG = g; h->swR = r; }
     }
   }
-  if (!choose_cfg(h->ld, 1, &h->swG, &h->swR, 16, nullptr, false)) return fail(HPF_ERR_UNSUPPORTED);
-  if (const char *e = getenv("HPF_PHI_CFG")) {
-    int g = 0, r = 0, v = 0;
-    if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&
-        (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && (uint32_t)(g * r * v) >= h->ld) {
-      h->phiG = g; h->phiR = r; h->phiV = v;
-    }
-  }
-  if (const char *e = getenv("HPF_SWEEP_CFG")) {
-    int g = 0, r = 0;
-    if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= 8 && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
-        (uint32_t)(g * r) >= h->ld) { h->swG = g; h->swR = r; }
-  }
-  if (const char *e = getenv("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
-  if (const char *e = getenv("HPF_HOT_BYTES")) { long long v = atoll(e); if (v >= 0) h->hot_bytes = (uint64_t)v; }
-  if (const char *e = getenv("HPF_HOT_FORCE")) h->hot_force = atoi(e) != 0;
-  if (const char *e = getenv("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
-  if (const char *e = getenv("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
-  if (const char *e = getenv("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
-  if (const char *e = getenv("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
+  if (const char *e = knob("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
+  if (const char *e = knob("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
+  if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
+  if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
+  if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
   h->u.rows = n; h->it.rows = m;
@@ -1345,16 +1212,8 @@ static int finish_upload(hpf_handle *h, uint64_t nnz)
   HIPCHK(h, hipMemcpyAsync(&last, h->colptr_dev + m, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if ((uint64_t)last != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
-  if (h->hot_bytes == 0) {
-    if ((rc = device_side_work(h, h->u, h->rowptr_dev, n))) return rc;
-    if ((rc = device_side_work(h, h->it, h->colptr_dev, m))) return rc;
-  } else {                                       // hot/cold experiment: reorders nonzeros on the host
-    std::vector<int64_t> rowptr((size_t)n + 1), colptr((size_t)m + 1);
-    if ((rc = d2h(h, rowptr.data(), h->rowptr_dev, ((size_t)n + 1) * 8))) return rc;
-    if ((rc = d2h(h, colptr.data(), h->colptr_dev, ((size_t)m + 1) * 8))) return rc;
-    if ((rc = upload_side_work(h, h->u, rowptr.data(), n, nnz, colptr.data(), m))) return rc;
-    if ((rc = upload_side_work(h, h->it, colptr.data(), m, nnz, rowptr.data(), n))) return rc;
-  }
+  if ((rc = device_side_work(h, h->u, h->rowptr_dev, n))) return rc;
+  if ((rc = device_side_work(h, h->it, h->colptr_dev, m))) return rc;
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nnz = nnz; h->have_csr = true;
@@ -1433,7 +1292,6 @@ int hpf_get_csc(hpf_handle *h, int64_t *colptr, uint32_t *users, uint8_t *vals)
 {
   if (!h) return HPF_ERR_INVALID;
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
-  if (h->it.phases != 1) { h->err = "the item-major view is reordered by the hot/cold split"; return HPF_ERR_UNSUPPORTED; }
   int rc;
   if (colptr && (rc = d2h(h, colptr, h->colptr_dev, ((size_t)h->it.rows + 1) * 8))) return rc;
   if (users && (rc = d2h(h, users, h->it.idx, (size_t)h->nnz * 4))) return rc;
@@ -1814,7 +1672,7 @@ int hpf_elbo(hpf_handle *h, double *out)
   if ((rc = refresh_elog(h, h->u))) return rc;
   if ((rc = refresh_elog(h, h->it))) return rc;
   // per-nonzero term: the user-major work list(s) of the phi pass, one wave per segment
-  const uint32_t nb_nnz = (uint32_t)std::min<uint64_t>(((uint64_t)h->u.nseg[0] + h->u.nseg[1] + 3) / 4 + 1, 16384);
+  const uint32_t nb_nnz = (uint32_t)std::min<uint64_t>(((uint64_t)h->u.nseg + 3) / 4 + 1, 16384);
   const uint32_t nb_g = 1024;
   double *part = nullptr, *Mt = nullptr, *Mb = nullptr;
   const size_t npart = (size_t)2 * nb_nnz + 2 * nb_g;
@@ -1832,20 +1690,20 @@ int hpf_elbo(hpf_handle *h, double *out)
       hipLaunchKernelGGL(rowmax_elog_kernel, dim3((h->it.rows + 255) / 256), dim3(256), 0, h->stream,
                          h->it.L, Mb, h->it.rows, h->ld, h->K, h->it.bias_col, h->it.junk_col);
     }
-    for (uint32_t ph = 0; ph < h->u.phases && from_w; ++ph) {
-      if (!h->u.nseg[ph]) continue;
+    if (from_w && h->u.nseg) {
+      const uint32_t ph = 0;
       ElboNnzWArgs a;
-      a.segs = h->u.segs[ph]; a.nseg = h->u.nseg[ph]; a.col = h->u.idx; a.val = h->u.val;
+      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.idx; a.val = h->u.val;
       a.Wt = (const double *)h->u.W; a.Wb = (const double *)h->it.W; a.Et = h->u.E; a.Eb = h->it.E;
       a.Mt = Mt; a.Mb = Mb;
       a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K;
       a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
       hipLaunchKernelGGL(elbo_nnz_w_kernel, dim3(nb_nnz), dim3(256), 0, h->stream, a);
     }
-    for (uint32_t ph = 0; ph < h->u.phases && h->nnz && !from_w; ++ph) {
-      if (!h->u.nseg[ph]) continue;
+    if (h->nnz && !from_w && h->u.nseg) {
+      const uint32_t ph = 0;
       ElboNnzArgs a;
-      a.segs = h->u.segs[ph]; a.nseg = h->u.nseg[ph]; a.col = h->u.idx; a.val = h->u.val;
+      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.idx; a.val = h->u.val;
       a.Lt = h->u.L; a.Lb = h->it.L; a.Et = h->u.E; a.Eb = h->it.E;
       a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K; a.C = h->C;
       a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
@@ -2018,12 +1876,12 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   if (!h || !out) return HPF_ERR_INVALID;
   memset(out, 0, sizeof *out);
   out->nnz = h->nnz;
-  out->user_segments = h->u.nseg[0] + h->u.nseg[1];
-  out->user_long_rows = h->u.nlong[0] + h->u.nlong[1] + h->u.nhuge[0] + h->u.nhuge[1];
-  out->user_huge_rows = h->u.nhuge[0] + h->u.nhuge[1];
-  out->item_segments = h->it.nseg[0] + h->it.nseg[1];
-  out->item_long_rows = h->it.nlong[0] + h->it.nlong[1] + h->it.nhuge[0] + h->it.nhuge[1];
-  out->item_huge_rows = h->it.nhuge[0] + h->it.nhuge[1];
+  out->user_segments = h->u.nseg;
+  out->user_long_rows = h->u.nlong + h->u.nhuge;
+  out->user_huge_rows = h->u.nhuge;
+  out->item_segments = h->it.nseg;
+  out->item_long_rows = h->it.nlong + h->it.nhuge;
+  out->item_huge_rows = h->it.nhuge;
   out->phi_G = (uint32_t)h->phiG; out->phi_R = (uint32_t)h->phiR; out->phi_V = (uint32_t)h->phiV;
   out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;
   out->ld = h->ld;

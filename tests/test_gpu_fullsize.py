@@ -183,8 +183,10 @@ def _device_model(cfg, n_loc, rowptr, col, val, row0, n_total, n_ranks=1, rank=0
     dev = rowptr.device
     m, K = cfg["m"], cfg["K"]
     D = Hpf(n_loc, m, K, hier=True, binary=cfg["binary"], n_ranks=n_ranks, rank=rank, n_users_total=n_total)
-    if xbuf is not None:
-        D.bind_exchange_buffer(xbuf.data_ptr(), xbuf.numel())
+    if xbuf is not None:                 # a list: receives the caller-owned exchange buffer [m x ld | ld]
+        x = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
+        D.bind_exchange_buffer(x.data_ptr(), x.numel())
+        xbuf.append(x)
     D.upload_csr_device(rowptr, col, val)
     st = synth.initial_state_device(n_loc, K, seeds[0], dev, row0=row0)
     D.set_state_device("THETA_E", st["E"]); D.set_state_device("THETA_ELOG", st["Elog"])
@@ -278,10 +280,8 @@ def test_c3_whole_properties():
     shards, xb = [], []
     for r, (a, b) in enumerate(parts):
         lo, hi = int(rowptr[a]), int(rowptr[b])
-        x = torch.zeros((m + 1) * K, dtype=torch.float64, device=dev)       # [m x ld | ld], ld = K = 100
         shards.append(_device_model(cfg, b - a, (rowptr[a:b + 1] - rowptr[a]).contiguous(), col[lo:hi], val[lo:hi],
-                                    a, n, 2, r, x))
-        xb.append(x)
+                                    a, n, 2, r, xb))
     assert abs((int(rowptr[parts[0][1]]) - nnz // 2)) < 4 * m                # balanced by nonzeros, not by users
     for _ in range(2):
         for S in shards:

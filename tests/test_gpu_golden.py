@@ -72,7 +72,7 @@ def test_softmax_golden_through_phi_passes(width, cases):
     D.set_state("BETA_ELOG", np.zeros((n, K)))
     D.iterate_local_phi()
     D.synchronize()
-    ld = (K + 1) & ~1
+    ld = D.work_info()["ld"]
     raw_items = D.exchange_read()[: n * ld].reshape(n, ld)[:, :K]      # item phi sums, no prior
     assert _close(raw_items, want), np.max(np.abs(raw_items - want) / np.maximum(np.abs(want), 1e-300))
     D.iterate_local_sweep()

@@ -116,9 +116,10 @@ def test_transfer_carriers_move_the_same_bytes(monkeypatch, mode):
     pinned double buffer, or pinning the caller's pages); sizes straddle the
     64 MiB staging buffer and the 1 MiB small-copy cut"""
     from hgaprec_amd.capi import Hpf
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     monkeypatch.setenv("HPF_H2D", mode)
     rng = np.random.default_rng(5)
-    n, m, K = 90_000, 50, 101                   # odd K: rows are padded (ld = 102), 72.7 MB per array
+    n, m, K = 90_000, 50, 101                   # rows are padded to the kernel shape (ld = 112), 72.7 MB per array
     D = Hpf(n, m, K, hier=True, bias=False)
     a = rng.random((n, K))
     D.set_state("THETA_E", a)
@@ -127,7 +128,7 @@ def test_transfer_carriers_move_the_same_bytes(monkeypatch, mode):
     D.set_state("XI_E", x)
     assert np.array_equal(D.get_state("XI_E"), x)
     D.close()
-    n, K = 100_000, 100                         # ld == K: straight copy, 80 MB
+    n, K = 100_000, 100                         # 80 MB
     D = Hpf(n, m, K, hier=True, bias=False)
     a = rng.random((n, K))
     D.set_state("THETA_ELOG", a)
@@ -143,6 +144,7 @@ def test_transfer_carriers_move_the_same_bytes(monkeypatch, mode):
 
 def test_work_info_reports_the_cut(monkeypatch):
     from hgaprec_amd.capi import Hpf
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     monkeypatch.setenv("HPF_SEG_MAX", "16")
     monkeypatch.setenv("HPF_HUGE_SLOTS", "8")
     n, m = 400, 3000
@@ -150,9 +152,33 @@ def test_work_info_reports_the_cut(monkeypatch):
     D = Hpf(n, m, 12, hier=True, bias=True)
     D.upload_csr(rowptr, col, val)
     w = D.work_info()
-    assert w["nnz"] == rowptr[-1] and w["ld"] == 14
+    assert w["nnz"] == rowptr[-1]
+    assert w["ld"] == w["phi_G"] * w["phi_R"] * w["phi_V"] == w["sweep_G"] * w["sweep_R"] >= 14
     assert w["user_huge_rows"] >= 1 and w["item_huge_rows"] >= 1          # m / 16 and n / 16 segments > 8
     assert w["user_long_rows"] >= w["user_huge_rows"]
     assert w["user_segments"] >= n and w["item_segments"] >= m
-    assert w["phi_G"] * w["phi_R"] * w["phi_V"] >= w["ld"]
     D.close()
+
+
+def test_stray_tuning_variables_are_ignored(monkeypatch):
+    """the library reads its tuning knobs only under HPF_EXPERIMENTAL=1: a stray
+    variable in a production environment changes neither the cut nor the layout"""
+    from hgaprec_amd.capi import Hpf
+    n, m = 400, 3000
+    rowptr, col, val = make_problem(n, m, 2000, seed=31, heavy_user=True, heavy_item=True)
+
+    def info():
+        D = Hpf(n, m, 12, hier=True, bias=True)
+        D.upload_csr(rowptr, col, val)
+        w = D.work_info()
+        D.close()
+        return w
+    base = info()
+    monkeypatch.setenv("HPF_SEG_MAX", "16")
+    monkeypatch.setenv("HPF_HUGE_SLOTS", "8")
+    monkeypatch.setenv("HPF_PHI_CFG", "16,1,2")
+    monkeypatch.setenv("HPF_GRAPH", "0")
+    assert info() == base
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+    w = info()
+    assert w["user_segments"] > base["user_segments"] and w["ld"] == 32 and w["graph_replay"] == 0

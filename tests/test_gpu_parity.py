@@ -86,6 +86,7 @@ def test_one_user_holds_most_ratings(orc, monkeypatch, huge_slots):
     # rated by every user.  Its row is cut into hundreds of segments whose
     # partial sums are combined in two levels (groups of partials, then the
     # group sums) once it has more than HPF_HUGE_SLOTS segments.
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     monkeypatch.setenv("HPF_SEG_MAX", "16")
     monkeypatch.setenv("HPF_HUGE_SLOTS", str(huge_slots))
     n, m, K = 400, 3000, 12
@@ -152,6 +153,7 @@ def test_graph_replay_equals_eager_launches(orc, monkeypatch, bias):
     # launch-bound; same kernels, same order => identical bits, and get/set
     # between calls still works.  Replayed iterations report only their total.
     outs, tms = [], []
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     for mode in ("0", "1"):
         monkeypatch.setenv("HPF_GRAPH", mode)
         M, D = _run_pair(orc, 400, 300, 20, 9000, True, bias, False, 5, seed=4)
@@ -321,26 +323,6 @@ def test_set_elog_again_mid_run(orc):
     D.iterate(2)
     for w in compare_states(True, True):
         assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
-
-
-@pytest.mark.parametrize("bias", [False, True])
-def test_hot_cold_two_phase_pass(orc, monkeypatch, bias):
-    # force the L2 hot/cold split of the phi passes (normally only chosen at
-    # scale) with a 12-row hot set and short segments, so that hot parts, cold
-    # parts, empty cold parts and long rows in both phases all occur
-    K = 12
-    ld = (K + (2 if bias else 0) + 1) & ~1
-    monkeypatch.setenv("HPF_HOT_BYTES", str(12 * ld * 8))
-    monkeypatch.setenv("HPF_HOT_FORCE", "1")
-    monkeypatch.setenv("HPF_SEG_MAX", "32")
-    M, D = _run_pair(orc, 700, 300, K, 16000, True, bias, False, 4, seed=23,
-                     prob_kw=dict(heavy_user=True, heavy_item=True, singles=True))
-    for it in range(4):
-        M.iterate(1)
-        D.iterate(1)
-    for w in compare_states(True, bias):
-        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
-    assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
 
 
 def test_library_rccl_allreduce_world1(orc):
