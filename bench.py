@@ -15,7 +15,12 @@ hpf_upload_csr_device / hpf_set_state_device: no PCIe inside or before `value`).
           nnz-balanced user range (partition_users), items are replicated, and
           the item-side shape sums (800 MB) + sum_u E[theta_u] go through one
           RCCL all-reduce per iteration, started right after the item-major
-          phi pass so that it travels underneath the user-major half.
+          phi pass so that it travels underneath the user-major half (and a tiny
+          second one for sum_u E[theta]); --single-allreduce fuses both into one
+          call after the user half, as BASELINE.json words it (no overlap).
+          Rank 0 then times the WHOLE matrix on its own GPU in the same process
+          (outside the timed region): `speedup_vs_1gpu_same_workload` needs no
+          stored number; `rccl` says what the communicator saw.
   --weak  the round-1 mode: every rank owns a C2-sized shard (weak scaling).
 
 Rank 0 prints one JSON line.
@@ -126,6 +131,10 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
                          "single-GPU smoke test of the N>1 code path)")
+    ap.add_argument("--single-allreduce", action="store_true",
+                    help="N > 1: ONE all-reduce of [m x ld | ld] after the user half instead of the overlapped pair")
+    ap.add_argument("--no-1gpu-reference", action="store_true",
+                    help="N > 1: skip rank 0's same-run timing of the whole matrix on one GPU")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -168,6 +177,16 @@ def main():
     # the RCCL calls and the stream ordering
     force_dist = os.environ.get("HPF_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    rccl_log = None
+    if use_dist and args.backend == "nccl" and rank == 0:
+        # what RCCL itself reports (ranks, channels, transports, algorithm / protocol of the
+        # big all-reduce) goes to a file that the `rccl` block of the JSON line quotes
+        rccl_log = f"/tmp/hpf_rccl_{os.getpid()}.log"
+        if os.environ.get("NCCL_DEBUG", "INFO") != "INFO":
+            log(f"[rank 0] NCCL_DEBUG={os.environ['NCCL_DEBUG']} overridden with INFO for the rccl block")
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,TUNING"
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -210,7 +229,10 @@ def main():
                                                  seed=cfg["seed"], device=dev, binary=cfg["binary"],
                                                  user_range=(ua, ub), deg=deg)
         # every rank must have cut the same matrix the same way
-        sig = torch.stack([deg.sum(), (deg * torch.arange(1, n_total + 1, device=dev)).sum() % 1_000_000_007]).to(torch.float64)
+        import zlib
+        cdf_sig = zlib.crc32(synth.item_cdf(m, cfg["alpha_i"]).numpy().tobytes())      # the item popularity table, bit for bit
+        sig = torch.stack([deg.sum(), (deg * torch.arange(1, n_total + 1, device=dev)).sum() % 1_000_000_007,
+                           torch.tensor(cdf_sig, device=dev)]).to(torch.float64)
         del deg
         hi_, lo_ = sig.clone(), sig.clone()
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
@@ -251,23 +273,25 @@ def main():
     t0 = time.perf_counter()
     ss = cfg["seed"] + state_seed_shift
 
-    def put(names, st):
-        for w, k in names:
-            D.set_state_device(w, st[k])
+    def start_state(H, rows, first_row, seed_users):
+        def put(names, st):
+            for w, k in names:
+                H.set_state_device(w, st[k])
+        put((("THETA_SHAPE", "shape"), ("THETA_E", "E"), ("THETA_ELOG", "Elog")),
+            synth.initial_state_device(rows, K, seed_users + 17, dev, row0=first_row))
+        put((("BETA_SHAPE", "shape"), ("BETA_E", "E"), ("BETA_ELOG", "Elog")),
+            synth.initial_state_device(m, K, cfg["seed"] + 29, dev))
+        if cfg["hier"]:
+            put((("XI_E", "E"),), synth.initial_state_device(rows, K, seed_users + 31, dev, prior_v=K, row0=first_row))
+            put((("ETA_E", "E"),), synth.initial_state_device(m, K, cfg["seed"] + 37, dev, prior_v=K))
+        if cfg["bias"]:
+            put((("UBIAS_E", "E"), ("UBIAS_ELOG", "Elog"), ("UBIAS_SHAPE", "shape")),
+                synth.initial_state_device(rows, K, seed_users + 41, dev, prior_v=m, row0=first_row))
+            put((("IBIAS_E", "E"), ("IBIAS_ELOG", "Elog"), ("IBIAS_SHAPE", "shape")),
+                synth.initial_state_device(m, K, cfg["seed"] + 43, dev, prior_v=n_total))
+        torch.cuda.empty_cache()
 
-    put((("THETA_SHAPE", "shape"), ("THETA_E", "E"), ("THETA_ELOG", "Elog")),
-        synth.initial_state_device(n_loc, K, ss + 17, dev, row0=row0))
-    put((("BETA_SHAPE", "shape"), ("BETA_E", "E"), ("BETA_ELOG", "Elog")),
-        synth.initial_state_device(m, K, cfg["seed"] + 29, dev))
-    if cfg["hier"]:
-        put((("XI_E", "E"),), synth.initial_state_device(n_loc, K, ss + 31, dev, prior_v=K, row0=row0))
-        put((("ETA_E", "E"),), synth.initial_state_device(m, K, cfg["seed"] + 37, dev, prior_v=K))
-    if cfg["bias"]:
-        put((("UBIAS_E", "E"), ("UBIAS_ELOG", "Elog"), ("UBIAS_SHAPE", "shape")),
-            synth.initial_state_device(n_loc, K, ss + 41, dev, prior_v=m, row0=row0))
-        put((("IBIAS_E", "E"), ("IBIAS_ELOG", "Elog"), ("IBIAS_SHAPE", "shape")),
-            synth.initial_state_device(m, K, cfg["seed"] + 43, dev, prior_v=n_total))
-    torch.cuda.empty_cache()
+    start_state(D, n_loc, row0, ss)
     t_state = time.perf_counter() - t0
     log(f"[rank {rank}] device hand-over: csr {t_upload:.2f}s, state {t_state:.2f}s")
 
@@ -281,10 +305,14 @@ def main():
             # (ld doubles) follows in a second, tiny one.  The item update then
             # consumes the NEW theta sums, like hgaprec.cc:1380-1386.
             D.iterate_local_items()
-            w = dist.all_reduce(x_items, async_op=True)
-            D.iterate_local_users()
-            dist.all_reduce(x_tail)
-            w.wait()
+            if args.single_allreduce:
+                D.iterate_local_users()
+                dist.all_reduce(xbuf)
+            else:
+                w = dist.all_reduce(x_items, async_op=True)
+                D.iterate_local_users()
+                dist.all_reduce(x_tail)
+                w.wait()
             D.iterate_global()
 
     def fence():
@@ -330,6 +358,50 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         replica_check = "ok" if bool(torch.equal(hi, lo)) and bool(torch.isfinite(hi).all()) else "MISMATCH"
         del be
+
+    rccl = None
+    if use_dist:
+        # what the communicator really was: ranks RCCL saw, its version, and
+        # the big all-reduce on its own -- same tensor size, nothing else on the GPU
+        scratch = torch.zeros_like(x_items)
+        dist.all_reduce(scratch)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(scratch)
+        e1.record()
+        e1.synchronize()
+        ar_ms = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        ar_ms = float(ar_ms.item())
+        nbytes = scratch.numel() * 8
+        del scratch
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "version": ver,
+                "item_allreduce_bytes": nbytes, "item_allreduce_alone_ms": round(ar_ms, 3),
+                # ring bus bandwidth, 2 (N-1)/N x bytes / time (the per-link figure xGMI is judged by)
+                "bus_GBps": round(2 * (world - 1) / max(world, 1) * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
+                "mode": "one fused all-reduce after the user half" if args.single_allreduce
+                        else "item sums all-reduced underneath the user half + a tail of ld doubles"}
+        if rccl_log and rank == 0:
+            try:
+                txt = Path(rccl_log).read_text(errors="replace").splitlines()
+                pick = lambda pat: [ln.split("NCCL INFO", 1)[-1].strip() for ln in txt if pat in ln]
+                rccl["log"] = {
+                    "init": (pick("Init COMPLETE") or pick("comm 0x"))[:2],
+                    "channels": pick("Connected all rings")[:1] + pick("Channel 00")[:2],
+                    # the line RCCL's tuner prints for the largest message it saw
+                    "allreduce_tuning": sorted(set(pick("AllReduce:")), key=len)[-2:],
+                    "lines": len(txt)}
+            except Exception as ex:
+                rccl["log"] = {"error": str(ex)}
 
     # the timed iterations did the work: every nonzero's phi sums to max(y, 1), so
     # the shape rows of this rank's users must hold exactly that mass (+ priors)
@@ -400,6 +472,16 @@ def main():
             kname, kbytes = "whole iteration (hipGraph replay)", ab["phi_user"] + ab["phi_item"] + ab["rows"]
         achieved = kbytes / (kms * 1e-3) / 1e9
         traffic, traffic_note = (None, "custom workload") if custom or world > 1 else measured_traffic(cname, kern)
+        # What bounds the kernel.  `traffic` is what crossed from the fabric
+        # into the XCDs' L2s (FETCH_SIZE counts Infinity-Cache hits too): when that rate is above
+        # what a device copy reaches on this GPU, part of it was served by the Infinity Cache and
+        # the pass is bound by the rate at which L2 misses are filled, not by DRAM alone.
+        fabric_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
+        hbm_only, hbm_only_note = measured_traffic("C3", "phi_item_hbm_only_GBps")
+        if fabric_gbs and copy_gbs and fabric_gbs > copy_gbs:
+            bound = "fabric request rate (HBM + Infinity Cache)"
+        else:
+            bound = "hbm"
         # bytes the sweeps really move: read the raw sums, write W (16 B per element);
         # SURVEY.md's formula credits 32 (it assumes shape, rate, E and Elog all materialised)
         Kp = K + (1 if cfg["bias"] else 0)
@@ -411,7 +493,7 @@ def main():
         per_kernel = None if graph else {
             "phi_item": {"algorithmic_bytes": ab["phi_item"], "ms": round(tm["phi_item_ms"], 4),
                          "GBps": gbs(ab["phi_item"], tm["phi_item_ms"]),
-                         "note": "gathers rows of the user matrix: HBM-bound"},
+                         "note": "gathers rows of the user matrix (>> Infinity Cache): L2-miss fills from HBM"},
             "phi_user": {"algorithmic_bytes": ab["phi_user"], "ms": round(tm["phi_user_ms"], 4),
                          "GBps": gbs(ab["phi_user"], tm["phi_user_ms"]),
                          "note": "CACHE-INCLUSIVE: its gathers of item rows are largely served by L2 / Infinity "
@@ -446,12 +528,19 @@ def main():
                 if use_dist else "single GPU",
             },
             "roofline": {
-                "bound": "hbm", "kernel": kname,
+                "bound": bound, "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                 "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                 "traffic": traffic, "traffic_source": traffic_note,
+                # traffic / launch time: cache-inclusive (Infinity-Cache hits are counted by FETCH_SIZE)
+                "fabric_side_GBps": fabric_gbs,
+                # the same kernel where nothing it gathers can be cache-resident (whole C3: 9 GB of
+                # user rows, uniform degrees), algorithmic bytes / time, from the profile named
+                "hbm_only_frac": (hbm_only / HBM_PEAK_GBS) if hbm_only else None,
+                "hbm_only_source": hbm_only_note if hbm_only else "no DRAM-side counter in rocprofv3 -L on gfx950; "
+                                   "no whole-C3 profile of this kernel source in profiles/traffic.json",
                 "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
                 "hbm_copy_measured_GBps": copy_gbs,
                 "per_kernel": per_kernel,
@@ -473,16 +562,8 @@ def main():
             out["exposed_allreduce_ms"] = {"max": max(r["exchange_wait_ms"] for r in per_rank),
                                            "mean": sum(r["exchange_wait_ms"] for r in per_rank) / world}
             out["compute_ms"] = {"max": max(comp), "min": min(comp)}
-            ref = ROOT / "profiles" / "c3_1gpu_reference.json"
-            if strong and not custom and cname == "C3" and ref.exists():
-                try:
-                    r1 = json.loads(ref.read_text())
-                    out["speedup_vs_1gpu_same_workload"] = {
-                        "value": r1["ms_per_step"] / out["ms_per_step"], "one_gpu_ms_per_step": r1["ms_per_step"],
-                        "source": "profiles/c3_1gpu_reference.json (whole C3 on one MI355X: "
-                                  "python bench.py --config C3 --steps 5 --warmup 2)"}
-                except Exception:
-                    pass
+        if rccl is not None:
+            out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline and not force_dist:
             s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
             s_users = min(s_users, n_loc)
@@ -490,8 +571,44 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, rowptr[: s_users + 1].cpu().numpy(),
                                                col[:nz].cpu().numpy().view(np.uint32),
                                                None if val is None else val[:nz].cpu().numpy())
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
     D.close()
+    if rank == 0 and strong and not args.no_1gpu_reference:
+        # the SAME matrix, whole, on this rank's GPU, timed by the same clock in the same
+        # process: the strong-scaling ratio then rests on nothing stored
+        try:
+            del rowptr, col, val
+            xbuf = x_items = x_tail = None
+            torch.cuda.empty_cache()
+            need = (n_total + m) * wi["ld"] * 8 * 4 + cfg["nnz"] * 12
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            if need > 0.85 * free_b:
+                raise RuntimeError(f"whole matrix needs ~{need / 1e9:.0f} GB, {free_b / 1e9:.0f} GB free")
+            rp1, c1, v1 = synth.generate_device(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                                seed=cfg["seed"], device=dev, binary=cfg["binary"])
+            D1 = Hpf(n_total, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
+                     stream=stream.cuda_stream, w_storage=1 if args.w32 else 0)
+            D1.upload_csr_device(rp1, c1, v1)
+            nnz1 = int(rp1[-1])
+            del rp1, c1, v1
+            start_state(D1, n_total, 0, cfg["seed"])
+            steps1 = max(2, min(args.steps, 5))
+            D1.iterate(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D1.iterate(steps1)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t0) / steps1 * 1e3
+            tm1 = D1.mean_timing(steps1)
+            D1.close()
+            out["speedup_vs_1gpu_same_workload"] = {
+                "value": ms1 / out["ms_per_step"], "one_gpu_ms_per_step": ms1, "one_gpu_nnz": nnz1,
+                "one_gpu_kernels_ms": {k: round(v, 3) for k, v in tm1.items() if k.endswith("_ms")},
+                "source": f"same run: rank 0 timed {steps1} iterations of the whole matrix on its own GPU after the "
+                          "timed region (the other ranks wait)"}
+        except Exception as ex:
+            out["speedup_vs_1gpu_same_workload"] = {"value": None, "source": f"same-run reference failed: {ex}"}
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

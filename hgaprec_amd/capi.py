@@ -49,6 +49,7 @@ class HpfConfig(C.Structure):
         ("binary", C.c_uint32), ("n_users_total", C.c_uint32), ("device", C.c_int32),
         ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("w_storage", C.c_uint32),
         ("stream", C.c_void_p), ("s_prior", C.c_double), ("r_prior", C.c_double),
+        ("novb", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -162,7 +163,7 @@ class Hpf:
 
     def __init__(self, n_users, n_items, K, hier=True, bias=False, binary=False,
                  device=0, stream=None, n_ranks=1, rank=0, n_users_total=0,
-                 s_prior=0.3, r_prior=0.3, w_storage=0):
+                 s_prior=0.3, r_prior=0.3, w_storage=0, novb=False):
         self.lib = load_library()
         cfg = HpfConfig()
         cfg.struct_size = C.sizeof(HpfConfig)
@@ -173,8 +174,10 @@ class Hpf:
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.s_prior, cfg.r_prior = float(s_prior), float(r_prior)
         cfg.w_storage = int(w_storage)
+        cfg.novb = int(bool(novb))
         self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(K)
         self.hier, self.bias, self.binary = bool(hier), bool(bias), bool(binary)
+        self.device = int(device)            # the HIP ordinal every device pointer handed in must live on
         self._h = C.c_void_p()
         rc = self.lib.hpf_create(C.byref(cfg), C.byref(self._h))
         if rc != HPF_OK:
@@ -204,6 +207,12 @@ class Hpf:
     def __exit__(self, *exc):
         self.close()
 
+    def _on_my_device(self, t, what):
+        """a raw data_ptr() of another GPU's memory would be a cross-device access (or a
+        fault) inside the library instead of an error here"""
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError(f"{what}: tensor on {t.device}, this handle runs on cuda:{self.device}")
+
     # -- data
     def upload_csr(self, rowptr, col, val=None):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
@@ -224,13 +233,19 @@ class Hpf:
         import torch
         if rowptr.dtype != torch.int64 or rowptr.numel() != self.n_users + 1 or not rowptr.is_cuda:
             raise ValueError("rowptr: int64 device tensor with n_users + 1 entries")
-        if col.dtype not in (torch.int32, torch.uint32) or not col.is_cuda:
+        u32 = getattr(torch, "uint32", None)              # absent before torch 2.3
+        if col.dtype not in tuple(d for d in (torch.int32, u32) if d is not None) or not col.is_cuda:
             raise ValueError("col: 32-bit device tensor")
         if val is not None and (val.dtype != torch.uint8 or not val.is_cuda or val.numel() != col.numel()):
             raise ValueError("val: uint8 device tensor as long as col")
+        for t, what in ((rowptr, "rowptr"), (col, "col"), (val, "val")):
+            if t is not None:
+                self._on_my_device(t, what)
         rowptr, col = rowptr.contiguous(), col.contiguous()
         val = None if val is None else val.contiguous()
         torch.cuda.synchronize(rowptr.device)             # the producer's work is complete
+        if int(rowptr[-1]) != col.numel() or int(rowptr[0]) != 0:     # the library reads rowptr[n] entries of col
+            raise ValueError(f"rowptr runs from {int(rowptr[0])} to {int(rowptr[-1])} but col has {col.numel()} entries")
         self._check(self.lib.hpf_upload_csr_device(
             self._h, C.c_void_p(rowptr.data_ptr()), C.c_void_p(col.data_ptr() if col.numel() else None),
             C.c_void_p(val.data_ptr()) if val is not None and val.numel() else None))
@@ -253,13 +268,17 @@ class Hpf:
         import torch
         if t.dtype != torch.float64 or not t.is_cuda or tuple(t.shape) != self.state_shape(which):
             raise ValueError(f"{which}: float64 device tensor of shape {self.state_shape(which)}")
+        self._on_my_device(t, which)
         t = t.contiguous()
         torch.cuda.synchronize(t.device)
         self._check(self.lib.hpf_set_state_device(self._h, STATE[which], C.c_void_p(t.data_ptr()), t.numel()))
 
     def get_state_device(self, which: str, device=None):
         import torch
-        out = torch.empty(self.state_shape(which), dtype=torch.float64, device=device or "cuda")
+        dev = torch.device("cuda", self.device) if device is None else torch.device(device)
+        if dev.type != "cuda" or (dev.index is not None and dev.index != self.device):
+            raise ValueError(f"{which}: asked for {dev}, this handle runs on cuda:{self.device}")
+        out = torch.empty(self.state_shape(which), dtype=torch.float64, device=torch.device("cuda", self.device))
         torch.cuda.synchronize(out.device)       # the block may still be in use by work queued on torch's stream
         self._check(self.lib.hpf_get_state_device(self._h, STATE[which], C.c_void_p(out.data_ptr()), out.numel()))
         return out

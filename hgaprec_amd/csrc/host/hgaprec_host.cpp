@@ -806,6 +806,7 @@ bool StopRule::update(uint32_t iter, double a, int *why)
 }  // namespace hgaprec
 
 #include <arpa/inet.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
@@ -840,7 +841,17 @@ int Comm::init(int rank_, int world_, const std::string &addr, int port, uint64_
   struct Hello { int32_t rank; uint32_t magic; uint64_t nonce; };
   const uint32_t magic = 0x48504631u;                      // "HPF1"
   sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
-  if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) return -1;
+  if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) {
+    // launchers commonly export a NAME (localhost, the node's hostname): resolve it
+    addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+    addrinfo *res = nullptr;
+    if (getaddrinfo(addr.c_str(), nullptr, &hints, &res) != 0 || !res) {
+      fprintf(stderr, "error: MASTER_ADDR '%s' is neither an IPv4 address nor a name that resolves to one\n", addr.c_str());
+      return -2;
+    }
+    sa.sin_addr = ((sockaddr_in *)res->ai_addr)->sin_addr;
+    freeaddrinfo(res);
+  }
   if (rank == 0) {
     int ls = ::socket(AF_INET, SOCK_STREAM, 0);
     if (ls < 0) return -1;

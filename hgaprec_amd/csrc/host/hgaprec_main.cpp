@@ -138,6 +138,7 @@ struct Driver {
     cfg.struct_size = sizeof cfg;
     cfg.n_users = hi - lo; cfg.n_items = m; cfg.K = k;
     cfg.hier = env.hier; cfg.bias = env.bias; cfg.binary = env.binary_data;
+    cfg.novb = env.vb ? 0u : 1u;              // read by the library only where the reference reads it (vb_bias)
     cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = (uint32_t)comm.world; cfg.rank = (uint32_t)comm.rank;
     cfg.s_prior = 0.3; cfg.r_prior = 0.3;
     int rc = hpf_create(&cfg, &h);
@@ -633,8 +634,10 @@ int main(int argc, char **argv)
   // -novb only changes the reference's behaviour in vb_bias() (-bias without -hier): there the
   // rates of BOTH sides are built from the previous iteration's expectations before anything is
   // swapped (hgaprec.cc:1276-1297, a Jacobi order); vb() and vb_hier() never read the flag.
-  // That ordering is not built here: refuse it instead of silently fitting the default order.
-  if (!env.vb && env.bias && !env.hier && env.unsupported.empty()) env.unsupported = "-novb (with -bias, without -hier)";
+  // The library runs that order on one GPU (hpf_config.novb); across ranks it would need the
+  // start state's sum_u E[theta] reduced before the first iteration, which is not built.
+  if (!env.vb && env.bias && !env.hier && (env.ngpus > 1 || world > 1) && env.unsupported.empty())
+    env.unsupported = "-novb with -bias, without -hier, on more than one GPU";
   if (!env.unsupported.empty()) {
     fprintf(stderr, "error: option %s selects a mode outside the MI355X hot-path build "
                     "(supported: -dir -n -m -k -hier -bias -binary-data -rfreq -max-iterations "

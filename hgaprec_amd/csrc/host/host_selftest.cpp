@@ -247,6 +247,24 @@ static void test_comm()
     CHECK(maxs[r] == 3.0);
     CHECK(got[r] == 0xabcdef01u);
   }
+  // MASTER_ADDR as a NAME (launchers export localhost / a host name): resolved, rank 0 listens;
+  // a name that does not resolve is an error of its own, not "cannot reach rank 0"
+  {
+    std::vector<int> ok2(2, 0);
+    auto two = [&](int rank) {
+      Comm c;
+      if (c.init(rank, 2, "localhost", port + 1, nonce)) return;
+      double v = rank + 1.0;
+      if (c.allreduce_sum(&v, 1) || v != 3.0) return;
+      c.close_all();
+      ok2[rank] = 1;
+    };
+    std::thread a(two, 0), b(two, 1);
+    a.join(); b.join();
+    CHECK(ok2[0] && ok2[1]);
+    Comm bad;
+    CHECK(bad.init(0, 2, "no-such-host.invalid", port + 2, nonce) == -2);
+  }
   // partition: every rank non-empty, boundaries monotone, balanced on nnz
   std::vector<int64_t> rp(1, 0);
   std::mt19937 g(2);

@@ -174,7 +174,7 @@ struct RadixArgs {
   const uint8_t  *vals_in;    // NULL with -binary-data
   const int64_t  *rowptr;     // [n+1], first pass only
   uint32_t        n_rows;
-  uint32_t       *keys_out;   // NULL on the last pass
+  uint32_t       *keys_out;   // always written: colptr_from_sorted_kernel reads the last pass's keys
   uint32_t       *users_out;
   uint8_t        *vals_out;
   const uint64_t *offsets;    // [digit][tile] exclusive scan of the counts

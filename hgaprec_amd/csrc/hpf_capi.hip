@@ -74,6 +74,10 @@ struct hpf_handle {
   bool own_stream = false;
   Side u, it;
   double *exch = nullptr; size_t exch_count = 0; bool exch_external = false;
+  // -novb with -bias and without -hier (vb_bias()'s else-branch, hgaprec.cc:1276-1297): the
+  // item rate is built from the sum_u E[theta] of BEFORE this iteration's user sweep
+  bool jacobi = false;
+  double *u_colsum_prev = nullptr;      // [ld]
   double *logfact = nullptr;
   int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ranking mask, CSC build)
   int64_t *colptr_dev = nullptr;   // item-major (CSC) column pointers, built on device
@@ -713,6 +717,15 @@ int prepare_derived(hpf_handle *h)
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
                        s.colsum_part, nb, h->ld, s.colsum);
   }
+  if (h->jacobi) {      // sum_u E[theta] of the start state: the first item rate uses it
+    Side &s = h->u;
+    if (!s.have_E) { h->err = "state not initialised: -novb needs THETA_E (the first item rate is built from it)"; return HPF_ERR_STATE; }
+    { int rc0 = refresh_es(h, s); if (rc0) return rc0; }
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(s.sweep_blocks), dim3(256), 0, h->stream, s.E, s.rows,
+                       h->ld, h->K, s.colsum_part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
+                       s.colsum_part, s.sweep_blocks, h->ld, s.colsum);
+  }
   int rc = check_launch(h, "prepare_derived");
   if (rc) return rc;
   h->derived_dirty = false;
@@ -816,6 +829,8 @@ int sweep_users(hpf_handle *h)
 {
   int rc;
   if (!h->capturing && h->phase != 2) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
+  if (h->jacobi)        // keep what _theta.sum_rows() still returns before _theta.swap() (hgaprec.cc:1281-1282)
+    HIPCHK(h, hipMemcpyAsync(h->u_colsum_prev, h->u.colsum, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum))) return rc;
   if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[5], h->stream));
@@ -850,7 +865,7 @@ int iterate_global(hpf_handle *h)
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
   if (!h->capturing && h->phase != 3) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
   if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
-  if ((rc = run_sweep(h, h->it, h->u.colsum, h->it.colsum))) return rc;
+  if ((rc = run_sweep(h, h->it, h->jacobi ? h->u_colsum_prev : h->u.colsum, h->it.colsum))) return rc;
   if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
   h->phase = 0;
@@ -940,6 +955,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (cfg->struct_size != sizeof(hpf_config)) return HPF_ERR_INVALID;
   if (cfg->K == 0 || cfg->n_items == 0) return HPF_ERR_INVALID;
   if (cfg->n_ranks == 0 || cfg->rank >= cfg->n_ranks) return HPF_ERR_INVALID;
+  const bool jacobi = cfg->novb && cfg->bias && !cfg->hier;       // the only place the reference reads Env::vb
+  if (jacobi && cfg->n_ranks != 1) return HPF_ERR_UNSUPPORTED;
   const uint32_t C = cfg->K + (cfg->bias ? 2u : 0u);
   if (C > HPF_MAX_COLUMNS) return HPF_ERR_UNSUPPORTED;
   int ndev = 0;
@@ -1060,6 +1077,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if ((rc = dalloc(h, &h->exch, h->exch_count))) return fail(rc);
   h->it.S = h->exch; h->u.colsum = h->exch + (size_t)m * ld;
   if ((rc = dalloc(h, &h->it.colsum, ld))) return fail(rc);
+  h->jacobi = jacobi;
+  if ((rc = dalloc(h, &h->u_colsum_prev, ld))) return fail(rc);
   // log y! as HGAPRec::log_factorial does it (hgaprec.cc:1563-1570)
   {
     double lf[256]; lf[0] = std::log(1.0); lf[1] = lf[0];
@@ -1091,7 +1110,7 @@ void hpf_destroy(hpf_handle *h)
   free_side(h->it, true);
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
-  dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->colptr_dev); dfree(h->flags);
+  dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->colptr_dev); dfree(h->flags); dfree(h->u_colsum_prev);
   for (int k = 0; k < 2; ++k) {
     if (h->stage[k]) (void)hipHostFree(h->stage[k]);
     if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
@@ -1471,8 +1490,14 @@ int hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t cou
 // ---- snapshot: the loop's device state, verbatim -------------------------------
 namespace {
 struct SnapHeader {
-  char magic[8];                        // "HPFSNAP1"
+  char magic[8];                        // "HPFSNAP2"
   uint32_t n_users, n_items, K, ld, hier, bias, w32, iterations;
+  // what else the state is only meaningful with: the priors, the job's shape and
+  // the ratings it was fitted to -- a snapshot of another data set of the same dimensions,
+  // or of another rank's shard, must not load
+  uint32_t n_users_total, rank, n_ranks, novb;
+  uint64_t nnz;
+  double s_prior, r_prior;
   uint32_t side_flags[2];               // bit 0 have_E, 1 have_L, 2 have_prior, 3 w_dirty, 4 l_stale, 5 es_stale,
                                         // 6 rate_set present, 7 prior_shape_set present
   uint32_t derived_dirty, pad;
@@ -1503,9 +1528,12 @@ uint32_t side_flag_word(const Side &s)
 void fill_snap_header(hpf_handle *h, SnapHeader *hd)
 {
   memset(hd, 0, sizeof *hd);
-  memcpy(hd->magic, "HPFSNAP1", 8);
+  memcpy(hd->magic, "HPFSNAP2", 8);
   hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
   hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->w32; hd->iterations = h->iterations;
+  hd->n_users_total = h->cfg.n_users_total; hd->rank = h->cfg.rank; hd->n_ranks = h->cfg.n_ranks;
+  hd->novb = h->jacobi ? 1u : 0u; hd->nnz = h->have_csr ? h->nnz : 0;
+  hd->s_prior = h->cfg.s_prior; hd->r_prior = h->cfg.r_prior;
   hd->side_flags[0] = side_flag_word(h->u); hd->side_flags[1] = side_flag_word(h->it);
   hd->derived_dirty = h->derived_dirty;
   hd->rate_set_count[0] = h->u.rate_set ? h->u.rate_set_count : 0;
@@ -1548,29 +1576,52 @@ int hpf_snapshot_save(hpf_handle *h, void *host, size_t bytes)
 int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
 {
   if (!h || !host || bytes < sizeof(SnapHeader)) return HPF_ERR_INVALID;
+  if (h->phase != 0 || h->items_reduce_pending) { h->err = "snapshot load inside an iteration"; return HPF_ERR_STATE; }
+  // ---- everything is validated before the handle is touched: a rejected blob leaves it as it was
   SnapHeader hd; memcpy(&hd, host, sizeof hd);
-  if (memcmp(hd.magic, "HPFSNAP1", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
+  if (memcmp(hd.magic, "HPFSNAP2", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
       hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (uint32_t)h->w32) {
     h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
   }
+  if (hd.s_prior != h->cfg.s_prior || hd.r_prior != h->cfg.r_prior || hd.n_users_total != h->cfg.n_users_total ||
+      hd.rank != h->cfg.rank || hd.n_ranks != h->cfg.n_ranks || hd.novb != (h->jacobi ? 1u : 0u)) {
+    h->err = "not a snapshot of this job (priors, rank layout or update order differ)"; return HPF_ERR_INVALID;
+  }
+  if (hd.nnz != (h->have_csr ? h->nnz : 0)) {
+    h->err = "the snapshot was taken on other ratings (nonzero count differs): upload the same CSR first"; return HPF_ERR_INVALID;
+  }
   Side *sides[2] = {&h->u, &h->it};
+  for (int k = 0; k < 2; ++k) {
+    const size_t lim = (size_t)sides[k]->rows * h->K;
+    const bool has = hd.side_flags[k] & 64u;
+    if (has != (hd.rate_set_count[k] != 0) || hd.rate_set_count[k] > lim) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
+  }
+  {
+    size_t tot = sizeof hd;
+    for (int k = 0; k < 2; ++k) {
+      const size_t mat = (size_t)sides[k]->rows * h->ld * 8, vec = (size_t)sides[k]->rows * 8, row = (size_t)h->ld * 8;
+      tot += 4 * mat + 5 * vec + 2 * row;
+      if (hd.side_flags[k] & 64u) tot += (size_t)hd.rate_set_count[k] * 8;
+      if (hd.side_flags[k] & 128u) tot += vec;
+    }
+    if (tot != bytes) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
+  }
   int rc;
+  double *new_rate[2] = {nullptr, nullptr}, *new_pss[2] = {nullptr, nullptr};
   for (int k = 0; k < 2; ++k) {                           // optional arrays the snapshot carries
     Side &s = *sides[k];
-    dfree(s.rate_set); s.rate_set = nullptr; s.rate_set_count = 0;
-    if (hd.side_flags[k] & 64u) {
-      const size_t lim = (size_t)s.rows * h->K;
-      if (hd.rate_set_count[k] == 0 || hd.rate_set_count[k] > lim) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
-      if ((rc = dalloc(h, &s.rate_set, (size_t)hd.rate_set_count[k]))) return rc;
-      s.rate_set_count = (size_t)hd.rate_set_count[k];
-    }
-    if ((hd.side_flags[k] & 128u) && !s.prior_shape_set && (rc = dalloc(h, &s.prior_shape_set, s.rows))) return rc;
+    rc = HPF_OK;
+    if ((hd.side_flags[k] & 64u)) rc = dalloc(h, &new_rate[k], (size_t)hd.rate_set_count[k]);
+    if (!rc && (hd.side_flags[k] & 128u) && !s.prior_shape_set) rc = dalloc(h, &new_pss[k], s.rows);
+    if (rc) { for (int j = 0; j < 2; ++j) { dfree(new_rate[j]); dfree(new_pss[j]); } return rc; }
+  }
+  for (int k = 0; k < 2; ++k) {
+    Side &s = *sides[k];
+    dfree(s.rate_set); s.rate_set = new_rate[k]; s.rate_set_count = (size_t)hd.rate_set_count[k];
+    if (new_pss[k]) s.prior_shape_set = new_pss[k];
   }
   std::vector<SnapSection> sec;
   snapshot_sections(h, hd.rate_set_count, hd.side_flags, &sec);
-  size_t tot = sizeof hd;
-  for (const SnapSection &x : sec) tot += x.bytes;
-  if (tot != bytes) { h->err = "damaged snapshot header"; return HPF_ERR_INVALID; }
   drop_graph(h);
   const char *p = (const char *)host + sizeof hd;
   for (const SnapSection &x : sec) {

@@ -77,15 +77,28 @@ def _perm(n, seed, device):
     return torch.sort(h, stable=True)[1]
 
 
+def _powerlaw_cpu(count, alpha):
+    """(rank+1)^-alpha for rank < count and its sum, in float64 ON THE HOST (numpy): the
+    floating-point part of the generator must not depend on which device runs the rest
+    -- pow and the order of a parallel sum differ between back ends"""
+    w = np.arange(1, count + 1, dtype=np.float64) ** (-float(alpha))
+    return w, float(np.sum(w))
+
+
 def degrees(n, m, nnz, alpha_u, seed, device="cpu"):
     """power-law user degrees d_u ~ (rank+1)^-alpha_u, 1 <= d_u <= m/2,
     sum(d) = nnz (when the caps allow), ranks permuted by a hash of the seed;
-    int64[n], identical on every device / rank"""
+    int64[n].  The real-valued targets are computed on the host, the rest is
+    integer arithmetic: identical on every device / rank."""
     device = torch.device(device)
     cap = max(1, m // 2)
-    w = torch.arange(1, n + 1, dtype=torch.float64, device=device) ** (-alpha_u)
-    t = w / w.sum() * nnz
-    d = torch.clamp(torch.floor(t), 1, cap).to(torch.int64)
+    w, wsum = _powerlaw_cpu(n, alpha_u)
+    t_h = w / wsum * float(nnz)
+    del w
+    fl_h = np.floor(t_h)
+    frac_all = torch.from_numpy(t_h - fl_h).to(device)
+    d = torch.clamp(torch.from_numpy(fl_h).to(device), 1, cap).to(torch.int64)
+    del t_h, fl_h
     for _ in range(16):
         rem = int(nnz) - int(d.sum())
         if rem == 0:
@@ -97,7 +110,7 @@ def degrees(n, m, nnz, alpha_u, seed, device="cpu"):
             if rem >= idx.numel():
                 d[idx] += torch.clamp(cap - d[idx], max=rem // idx.numel())
             else:
-                frac = (t - torch.floor(t))[idx]
+                frac = frac_all[idx]
                 d[idx[torch.sort(frac, descending=True, stable=True)[1][:rem]]] += 1
         else:
             idx = torch.nonzero(d > 1, as_tuple=False).flatten()
@@ -110,22 +123,32 @@ def degrees(n, m, nnz, alpha_u, seed, device="cpu"):
     return d[_perm(n, seed, device)]
 
 
+def item_cdf(m, alpha_i, device="cpu"):
+    """cumulative popularity of the items by rank, float64[m], built on the host in a
+    fixed (sequential) order and copied to `device`"""
+    p, psum = _powerlaw_cpu(m, alpha_i)
+    return torch.from_numpy(np.cumsum(p / psum)).to(torch.device(device))
+
+
 def generate_device(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=False,
-                    item_seed=None, topup_rounds=4, user_range=None, deg=None):
+                    item_seed=None, topup_rounds=4, user_range=None, deg=None, fill=True):
     """-> torch tensors on `device`: rowptr int64[b-a+1], col int32[nnz'],
     val uint8[nnz'] | None for users [a, b) = user_range (default: all) of the
     matrix G(seed, n, m, nnz, alpha_u, alpha_i).  Users get power-law degrees,
     items are drawn without replacement per user from a power-law popularity
-    (draw, dedupe, top up); columns sorted inside a row; col holds item ids
-    < m < 2^31.  `deg` may pass in degrees(...) already computed."""
+    (draw, dedupe, top up `topup_rounds` times; what a user still lacks after that
+    -- heavy users, whose draws keep hitting the same popular items -- is filled
+    with the most popular items the user does not have yet, so that every user
+    reaches the planned degree and the matrix the planned nnz); columns sorted
+    inside a row; col holds item ids < m < 2^31.  Every user's row is a function
+    of (seed, user) alone: user ranges generate independently.  `deg` may pass
+    in degrees(...) already computed."""
     device = torch.device(device)
     a, b = (0, n) if user_range is None else (int(user_range[0]), int(user_range[1]))
     d_all = degrees(n, m, nnz, alpha_u, seed, device) if deg is None else deg.to(device)
     d = d_all[a:b]
     del d_all
-    p = torch.arange(1, m + 1, dtype=torch.float64, device=device) ** (-alpha_i)
-    cdf = torch.cumsum(p / p.sum(), 0)
-    del p
+    cdf = item_cdf(m, alpha_i, device)
     iseed = int(seed if item_seed is None else item_seed) + 7919
     iperm = _perm(m, iseed, device)
     nloc = b - a
@@ -163,6 +186,8 @@ def generate_device(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", b
             drawn = drawn + need
             have = torch.bincount(keys // m - (a + ca), minlength=cb - ca)
             need = (dc - have).clamp(min=0)
+        if fill and int(need.sum()) > 0:
+            keys = _fill_by_popularity(keys, users, dc, need, iperm, m, a + ca)
         counts[ca:cb] = torch.bincount(keys // m - (a + ca), minlength=cb - ca)
         cols.append((keys % m).to(torch.int32))
         if not binary:
@@ -175,6 +200,47 @@ def generate_device(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", b
     col = cols[0] if len(cols) == 1 else torch.cat(cols)
     val = None if binary else (vals[0] if len(vals) == 1 else torch.cat(vals))
     return rowptr, col, val
+
+
+def _fill_by_popularity(keys, users, dc, need, iperm, m, user0, piece=400_000_000):
+    """users that still lack `need` items after the rejection rounds get the most popular
+    items they do not have yet.  The first d_u items in popularity order hold at most
+    (d_u - need_u) of the user's present items, hence at least need_u new ones: candidates
+    are those d_u items, the new ones among them are ranked, the first need_u are kept.
+    keys: sorted unique user * m + item of the chunk; returns the same with the fill."""
+    device = keys.device
+    sel = torch.nonzero(need > 0, as_tuple=False).flatten()
+    out = [keys]
+    # needy users in pieces of bounded candidate count
+    L = dc[sel]
+    cum = torch.cumsum(L, 0)
+    start = 0
+    while start < sel.numel():
+        base = int(cum[start - 1]) if start > 0 else 0
+        stop = int(torch.searchsorted(cum, torch.tensor(base + piece, device=device), right=True))
+        stop = min(sel.numel(), max(stop, start + 1))
+        ss = sel[start:stop]
+        Ls = dc[ss]
+        tot = int(Ls.sum())
+        first = torch.cumsum(Ls, 0) - Ls
+        owner = torch.repeat_interleave(torch.arange(ss.numel(), device=device), Ls)
+        rank = torch.arange(tot, device=device, dtype=torch.int64) - first[owner]
+        cand = users[ss][owner] * m + iperm[rank]
+        del rank
+        if keys.numel():
+            pos = torch.searchsorted(keys, cand).clamp(max=keys.numel() - 1)
+            new = keys[pos] != cand
+            del pos
+        else:
+            new = torch.ones_like(cand, dtype=torch.bool)
+        c = torch.cumsum(new.to(torch.int64), 0)
+        before = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), c])[first]   # new ones before the user's run
+        order = c - before[owner]                                 # 1-based index among the user's new candidates
+        keep = new & (order <= need[ss][owner])
+        out.append(cand[keep])
+        del cand, new, c, order, keep, owner
+        start = stop
+    return torch.unique(torch.cat(out))
 
 
 def generate(n, m, nnz, alpha_u=0.5, alpha_i=0.8, seed=0, device="cpu", binary=False,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 3
+#define HPF_ABI_VERSION 4
 
 typedef struct hpf_handle hpf_handle;
 
@@ -90,6 +90,14 @@ typedef struct {
   void    *stream;         /* hipStream_t to run on, NULL => own stream      */
   double   s_prior;        /* 0.3 (hgaprec.cc:13-20 hard-codes both)         */
   double   r_prior;        /* 0.3                                            */
+  uint32_t novb;           /* -novb (Env::vb == false).  Read only where the  */
+                           /* reference reads it: vb_bias(), i.e. bias without */
+                           /* hier (hgaprec.cc:1250,1276-1297) -- both rates   */
+                           /* are then built from the PREVIOUS iteration's     */
+                           /* expectations before anything is swapped (the     */
+                           /* item rate takes the old sum_u E[theta]).         */
+                           /* n_ranks must be 1 in that mode.                  */
+  uint32_t reserved;
 } hpf_config;
 
 /* per-kernel device time, milliseconds, from hipEvents recorded on the

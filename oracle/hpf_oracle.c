@@ -541,6 +541,7 @@ struct orc_model {
   orc_rng rng;
   double *phi, *tmpK, *tmpN;
   int skip_step_a;
+  int novb;                /* Env::vb == false (-novb); read by vb_bias() only */
 };
 
 orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
@@ -560,6 +561,8 @@ orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
   orc_rng_seed(&M->rng, 0);
   return M;
 }
+
+void orc_model_set_novb(orc_model *M, int novb) { M->novb = novb ? 1 : 0; }
 
 void orc_model_free(orc_model *M)
 {
@@ -679,9 +682,30 @@ static void iterate_hier(orc_model *M)  /* hgaprec.cc:1340-1414 */
   gp_swap(&M->eta); gp_compute_expectations(&M->eta);
 }
 
+/* vb_bias() with -novb: hgaprec.cc:1276-1297.  Both rates are built from the
+   expectations of the previous iteration -- _theta.sum_rows() runs before
+   _theta.swap() / compute_expectations() -- then everything is swapped. */
+static void iterate_flat_bias_novb(orc_model *M)
+{
+  const uint32_t K = M->K;
+  sweep_nonzeros(M);
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->beta, M->tmpK);                                   /* 1278-1280 */
+  for (uint32_t k = 0; k < K; ++k) M->theta.rnext[k] += M->tmpK[k];
+  memset(M->tmpK, 0, sizeof(double) * K);
+  gp_sum_rows(&M->theta, M->tmpK);                                  /* 1281-1283: the OLD E[theta] */
+  for (uint32_t k = 0; k < K; ++k) M->beta.rnext[k] += M->tmpK[k];
+  for (uint32_t i = 0; i < M->n; ++i) M->ubias.rnext[i] += M->m;    /* 1285-1286 */
+  for (uint32_t i = 0; i < M->m; ++i) M->ibias.rnext[i] += M->n;
+  gp_swap(&M->theta); gp_swap(&M->beta); gp_swap(&M->ubias); gp_swap(&M->ibias);   /* 1288-1291 */
+  gp_compute_expectations(&M->theta); gp_compute_expectations(&M->beta);            /* 1293-1296 */
+  gp_compute_expectations(&M->ubias); gp_compute_expectations(&M->ibias);
+}
+
 static void iterate_flat(orc_model *M)  /* vb(): hgaprec.cc:927-956 ; vb_bias(): 1226-1272 */
 {
   const uint32_t K = M->K;
+  if (M->bias && M->novb) { iterate_flat_bias_novb(M); return; }     /* if (_env.vb) ... else, hgaprec.cc:1250 */
   sweep_nonzeros(M);
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->beta, M->tmpK);
@@ -1203,6 +1227,7 @@ int orc_run(const orc_run_args *a)
 
   orc_model *M = orc_model_new(R->nusers, R->nitems, a->k, a->hier, a->bias, a->binary);
   orc_model_set_csr(M, R->rowptr, R->col, R->val);
+  orc_model_set_novb(M, a->novb);
   snprintf(p, sizeof p, "%s/validation.txt", a->outdir); FILE *vf = fopen(p, "w");
   snprintf(p, sizeof p, "%s/test.txt", a->outdir);       FILE *tf = fopen(p, "w");
   if (!vf || !tf) return -1;

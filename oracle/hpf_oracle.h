@@ -90,6 +90,8 @@ enum {
 orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
                          int binary);
 void orc_model_free(orc_model *M);
+/* Env::vb = !novb (main.cc:64,194); only vb_bias() reads it (hgaprec.cc:1250) */
+void orc_model_set_novb(orc_model *M, int novb);
 /* borrowed pointers; must outlive the model */
 void orc_model_set_csr(orc_model *M, const int64_t *rowptr, const uint32_t *col,
                        const uint8_t *val);
@@ -127,6 +129,7 @@ typedef struct {
   uint32_t max_iterations;
   double seed;
   int logl;                 /* -logl: append the bound to logl.txt at every report */
+  int novb;                 /* -novb */
 } orc_run_args;
 int orc_run(const orc_run_args *a);
 

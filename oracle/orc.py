@@ -33,7 +33,7 @@ class RunArgs(C.Structure):
         ("n", C.c_uint32), ("m", C.c_uint32), ("k", C.c_uint32),
         ("hier", C.c_int), ("bias", C.c_int), ("binary", C.c_int),
         ("rating_threshold", C.c_uint32), ("rfreq", C.c_uint32),
-        ("max_iterations", C.c_uint32), ("seed", C.c_double), ("logl", C.c_int),
+        ("max_iterations", C.c_uint32), ("seed", C.c_double), ("logl", C.c_int), ("novb", C.c_int),
     ]
 
 
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     L.orc_model_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]
     L.orc_model_new.restype = vp
     L.orc_model_free.argtypes = [vp]
+    L.orc_model_set_novb.argtypes = [vp, C.c_int]
     L.orc_model_set_csr.argtypes = [vp, C.POINTER(C.c_int64), u32p, C.POINTER(C.c_uint8)]
     L.orc_model_initialize.argtypes = [vp, C.c_double]
     L.orc_model_iterate.argtypes = [vp, C.c_int]
@@ -221,11 +222,12 @@ class Ratings:
 class Model:
     """CPU restatement of HGAPRec (vb_hier / vb / vb_bias)."""
 
-    def __init__(self, n, m, K, hier=True, bias=False, binary=False):
+    def __init__(self, n, m, K, hier=True, bias=False, binary=False, novb=False):
         self.L = lib()
         self.n, self.m, self.K = n, m, K
         self.hier, self.bias, self.binary = hier, bias, binary
         self._m = C.c_void_p(self.L.orc_model_new(n, m, K, int(hier), int(bias), int(binary)))
+        self.L.orc_model_set_novb(self._m, int(bool(novb)))       # Env::vb = !novb; vb_bias() alone reads it
         self._keep = None
 
     def set_csr(self, rowptr, col, val=None):
@@ -298,9 +300,9 @@ class Model:
 
 
 def run(datadir, outdir, n, m, k, hier=True, bias=False, binary=False,
-        rating_threshold=1, rfreq=10, max_iterations=1000, seed=0.0, logl=False):
+        rating_threshold=1, rfreq=10, max_iterations=1000, seed=0.0, logl=False, novb=False):
     a = RunArgs(str(datadir).encode(), str(outdir).encode(), n, m, k, int(hier), int(bias),
-                int(binary), rating_threshold, rfreq, max_iterations, float(seed), int(logl))
+                int(binary), rating_threshold, rfreq, max_iterations, float(seed), int(logl), int(bool(novb)))
     return lib().orc_run(C.byref(a))
 
 

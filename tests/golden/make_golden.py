@@ -158,7 +158,73 @@ def env_cases():
                       "Logger::initialize log.cc:9-118", "cases": cases}
 
 
+# ---------------------------------------------------------------------------
+# End-to-end fixtures from the WHOLE reference binary.  Needs
+# oracle/_ref/hgaprec_ref, which `make -C oracle ref-full` builds only where a genuine GSL
+# is installed -- not in this image, so nothing below has ever produced a file here and
+# end-to-end parity stays "unpinned" (DESIGN.md section 7).  On a machine with GSL:
+#     make -C oracle ref-full && python tests/golden/make_golden.py --full
+# writes tests/golden/full/<case>/{case.json, data/*.tsv}; tests/test_gpu_cli.py
+# (test_cli_matches_reference_fixtures) then runs the MI355X CLI on the same inputs.
+# ---------------------------------------------------------------------------
+REFBIN = ROOT / "oracle" / "_ref" / "hgaprec_ref"
+FULL_CASES = [   # name, (n, m, nnz, seed, problem kwargs), K, flags
+    ("F1_hier", (300, 200, 9000, 17, {}), 5, ["-hier", "-rfreq", "1", "-max-iterations", "20"]),
+    ("F2_hier_bias", (300, 200, 9000, 17, {}), 5, ["-hier", "-bias", "-rfreq", "1", "-max-iterations", "20"]),
+    ("F3_hier_binary", (300, 200, 9000, 17, {}), 5, ["-hier", "-binary-data", "-rating-threshold", "4", "-rfreq", "1", "-max-iterations", "20"]),
+    ("F4_vb", (300, 200, 9000, 17, {}), 5, []),
+    ("F4_vb_bias", (300, 200, 9000, 17, {}), 5, ["-bias"]),
+    ("F4_vb_bias_novb", (300, 200, 9000, 17, {}), 5, ["-bias", "-novb"]),
+    ("F5_k100", (500, 300, 20000, 23, {}), 100, ["-hier", "-rfreq", "2", "-max-iterations", "6"]),
+    ("F6_power_law", (400, 300, 12000, 31, {"heavy_user": True, "heavy_item": True, "singles": True}), 8,
+     ["-hier", "-rfreq", "2", "-max-iterations", "10"]),
+    ("F8_seed0", (300, 200, 9000, 17, {}), 5, ["-hier", "-rfreq", "1", "-max-iterations", "0", "-seed", "0"]),
+    ("F8_seed_2_31", (300, 200, 9000, 17, {}), 5, ["-hier", "-rfreq", "1", "-max-iterations", "0", "-seed", "2147483648"]),
+    ("F9_logl", (300, 200, 9000, 17, {}), 6, ["-hier", "-bias", "-logl", "-rfreq", "2", "-max-iterations", "8"]),
+]
+
+
+def full_fixtures():
+    sys.path.insert(0, str(ROOT))
+    from tests.test_gpu_cli import write_dataset
+    from tests.util import make_problem           # noqa: F401  (write_dataset draws from it)
+    out_root = GOLD / "full"
+    for name, (n, m, nnz, seed, kw), K, flags in FULL_CASES:
+        cdir = out_root / name
+        data = cdir / "data"
+        if cdir.exists():
+            import shutil
+            shutil.rmtree(cdir)
+        write_dataset(data, n, m, nnz, seed=seed, **kw)
+        ids = sorted({int(l.split("\t")[0]) for l in (data / "test.tsv").read_text().splitlines()})
+        (data / "test_users.tsv").write_text("".join(f"{u}\n" for u in ids[:60]))
+        args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K)] + (flags if "-seed" in flags else ["-seed", "7"] + flags)
+        with tempfile.TemporaryDirectory() as td:
+            r = subprocess.run([str(REFBIN)] + args, cwd=td, capture_output=True, text=True, timeout=3600)
+            if r.returncode != 0:
+                sys.exit(f"{name}: the reference exited with {r.returncode}\n{r.stderr[-2000:]}")
+            outs = [p for p in Path(td).iterdir() if p.is_dir()]
+            assert len(outs) == 1, outs
+            files = {}
+            for f in sorted(outs[0].iterdir()):
+                if f.suffix in (".tsv", ".txt") and f.stat().st_size:
+                    lines = f.read_text().splitlines()
+                    step = max(1, len(lines) // 400) if f.suffix == ".tsv" and len(lines) > 400 else 1
+                    files[f.name] = {"rows": len(lines), "every": step, "lines": lines[::step]}
+            case = {"source": "premgopalan/hgaprec built by oracle/Makefile ref-full against the installed GSL",
+                    "args": [a if a != str(data) else "DATA" for a in args], "prefix": outs[0].name,
+                    "n": n, "m": m, "K": K, "files": files}
+        (cdir / "case.json").write_text(json.dumps(case, indent=1))
+        print("wrote", cdir)
+
+
 def main():
+    if "--full" in sys.argv:
+        if not REFBIN.exists():
+            sys.exit("oracle/_ref/hgaprec_ref missing: `make -C oracle ref-full` builds it only where a genuine "
+                     "GSL is installed (this image has none); no end-to-end fixtures can be generated here")
+        full_fixtures()
+        return
     if not REFPART.exists():
         sys.exit("oracle/_ref/refpart missing: run `make -C oracle ref` where /root/reference exists")
     GOLD.mkdir(parents=True, exist_ok=True)

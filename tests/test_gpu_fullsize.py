@@ -28,6 +28,7 @@ def c2():
     dev = torch.device("cuda", 0)
     rowptr, col, val = synth.generate(cfg["n"], cfg["m"], cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
                                       seed=cfg["seed"], device=dev)
+    assert int(rowptr[-1]) == cfg["nnz"]                 # the generator reaches BASELINE's nnz
     st = {
         "theta": synth.initial_state(cfg["n"], cfg["K"], 1, dev),
         "beta": synth.initial_state(cfg["m"], cfg["K"], 2, dev),
@@ -133,6 +134,7 @@ def test_c4_bias_k200_properties():
     n, m, K = cfg["n"], cfg["m"], cfg["K"]
     dev = torch.device("cuda", 0)
     rowptr, col, val = synth.generate(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev)
+    assert abs(int(rowptr[-1]) - cfg["nnz"]) <= 1e-3 * cfg["nnz"]      # 1e8, heavy users included
     D = Hpf(n, m, K, hier=True, bias=True)
     D.upload_csr(rowptr, col, val)
     st = synth.initial_state(n, K, 1, dev)
@@ -228,7 +230,7 @@ def test_c3_whole_properties():
     rowptr, col, val = synth.generate_device(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=dev)
     torch.cuda.empty_cache()
     nnz = int(rowptr[-1])
-    assert nnz > 0.99e9
+    assert abs(nnz - cfg["nnz"]) <= 1e-3 * cfg["nnz"]
     w = torch.clamp(val, min=1).to(torch.float64)
     mass_u = _row_mass(rowptr, w)
     mass_i = torch.bincount(col.to(torch.int64), weights=w, minlength=m)
@@ -321,13 +323,15 @@ def test_c5_shard_full_size():
     planned = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(deg, 0, out=planned[1:])
     a, b = partition_users(planned.cpu().numpy(), 8)[0]
+    planned_nnz = int(planned[b] - planned[a])
     del planned
     rowptr, col, val = synth.generate_device(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"],
                                              device=dev, binary=True, user_range=(a, b), deg=deg)
     del deg
     torch.cuda.empty_cache()
     nnz = int(rowptr[-1])
-    assert val is None and 4.5e8 < nnz < 6.5e8 and 5_000_000 < b - a < 7_500_000
+    assert nnz == planned_nnz                            # every user reaches the planned degree
+    assert val is None and 5.5e8 < nnz < 7.0e8 and 4_000_000 < b - a < 7_500_000
     D = _device_model(cfg, b - a, rowptr, col, None, a, n, n_ranks=8, rank=0)
     wi = D.work_info()
     assert wi["item_huge_rows"] > 0, wi          # a blockbuster item: > 256 segments of 512 raters

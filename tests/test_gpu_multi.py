@@ -303,7 +303,8 @@ def test_range_generated_shards_equal_the_unsharded_run(world):
         S.close()
 
 
-def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo():
+@pytest.mark.parametrize("single", [False, True])
+def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo(single):
     """bench.py's strong-scaling path with two REAL ranks sharing GPU 0 (gloo carries the
     all-reduce; RCCL refuses two ranks on one device): each rank generates only its
     nnz-balanced user range of the same C3-shaped matrix (cut to 0.5 %), the ranks
@@ -314,11 +315,16 @@ def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "0.005",
-                        "--backend", "gloo", "--same-device"],
+                        "--backend", "gloo", "--same-device"] + (["--single-allreduce"] if single else []),
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["replica_check"] == "ok" and d["self_check"]["ok"]
+    # the line says what the communicator saw and carries its own one-GPU reference
+    assert d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["item_allreduce_alone_ms"] > 0
+    assert ("fused" in d["rccl"]["mode"]) == single
+    sp = d["speedup_vs_1gpu_same_workload"]
+    assert sp["source"].startswith("same run") and sp["value"] > 0 and sp["one_gpu_nnz"] == d["config"]["nnz_total"]
     assert d["config"]["workload"].startswith("C3")
     cfg = synth.CONFIGS["C3"]
     n, m, nnz = int(cfg["n"] * 0.005), int(cfg["m"] * 0.005), int(cfg["nnz"] * 0.005)
@@ -342,3 +348,6 @@ def test_one_gpu_bench_takes_the_distributed_path():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["replica_check"] == "ok" and d["self_check"]["ok"]
     assert d["roofline"]["traffic"] is None and "per_rank" in d
+    # a real (one-rank) RCCL communicator: its version and what its own log said
+    assert d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["version"]
+    assert d["rccl"]["log"].get("lines", 0) > 0, d["rccl"]

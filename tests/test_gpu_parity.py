@@ -67,6 +67,46 @@ def test_iterations_match_oracle(orc, K, hier, bias, binary):
         assert abs(ed - eo) <= 1e-10 * abs(eo), (it, ed, eo)
 
 
+def test_vb_bias_novb_uses_the_previous_iterations_sums(orc):
+    """-bias -novb without -hier: vb_bias()'s else-branch (hgaprec.cc:1276-1297).  Both rates
+    come from the expectations of the previous iteration -- the item rate takes
+    sum_u E[theta] of BEFORE the user update -- then everything is swapped."""
+    from hgaprec_amd.capi import Hpf
+    n, m, K = 300, 200, 7
+    rowptr, col, val = make_problem(n, m, 6000, 21)
+    M = orc.Model(n, m, K, False, True, False, novb=True)
+    M.set_csr(rowptr, col, val)
+    M.initialize(21)
+    M0 = orc.Model(n, m, K, False, True, False)          # the default (Gauss-Seidel) order, for contrast
+    M0.set_csr(rowptr, col, val)
+    M0.initialize(21)
+    D = Hpf(n, m, K, hier=False, bias=True, novb=True)
+    D.upload_csr(rowptr, col, val)
+    copy_state(M, D, False, True)
+    theta_e0 = M.state("THETA_E").copy()
+    for it in range(6):
+        M.iterate(1); M0.iterate(1); D.iterate(1)
+        for w in compare_states(False, True):
+            e = rel_err(D.get_state(w), M.state(w))
+            assert e < RTOL, f"iter {it} {w}: rel err {e:.3e}"
+        if it == 0:      # the first item rate is 0.3 + sum_u E[theta] of the START state
+            assert np.allclose(D.get_state("BETA_RATE"), 0.3 + theta_e0.sum(0), rtol=1e-12)
+    assert rel_err(M.state("BETA_E"), M0.state("BETA_E")) > 1e-3          # the order matters
+    D.close()
+    # with -hier the reference never reads the flag: identical bits with and without it
+    outs = []
+    for novb in (False, True):
+        D = Hpf(n, m, K, hier=True, bias=True, novb=novb)
+        D.upload_csr(rowptr, col, val)
+        Mh = orc.Model(n, m, K, True, True, False, novb=novb)
+        Mh.set_csr(rowptr, col, val); Mh.initialize(3)
+        copy_state(Mh, D, True, True)
+        D.iterate(3); Mh.iterate(3)
+        outs.append((D.get_state("BETA_E"), Mh.state("BETA_E").copy()))
+        D.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_power_law_long_rows_and_singletons(orc):
     # one user holding every item, one item rated by every user, users with a
     # single rating; rows longer than the segment cap (512) on both sides
@@ -207,6 +247,17 @@ def test_snapshot_restore_continues_bit_identically(orc, hier, bias):
     bad = blob.copy(); bad[0] ^= 1
     with pytest.raises(HpfError):
         B.restore(bad)
+    # nor a snapshot of another job of the same dimensions: other priors, other
+    # ratings, another rank's shard -- and a refused blob leaves the handle as it was
+    before = B.get_state("THETA_E")
+    for kw, other_data in ((dict(s_prior=0.4), False), (dict(n_ranks=2, rank=1, n_users_total=2 * n), False), ({}, True)):
+        F = Hpf(n, m, K, hier=hier, bias=bias, **kw)
+        rp2, c2, v2 = make_problem(n, m, 8000 if other_data else 9000, 15 if other_data else 14)
+        F.upload_csr(rp2, c2, v2)
+        with pytest.raises(HpfError):
+            F.restore(blob)
+        F.close()
+    assert np.array_equal(B.get_state("THETA_E"), before)
     # before the first iteration too: the start state itself round-trips
     M2, D = _run_pair(orc, n, m, K, 9000, hier, bias, False, 2, seed=14)
     E = Hpf(n, m, K, hier=hier, bias=bias)

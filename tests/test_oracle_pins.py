@@ -195,3 +195,34 @@ def test_model_rate_sums_are_the_pinned_loop(orc):
     tr = M.state("THETA_RATE")
     for k in range(K):
         assert tr[k] == 0.3 + orc.seq_sum(be.ravel()[k:], stride=K, n=m)
+
+
+def test_vb_bias_novb_branch_by_construction(orc):
+    """vb_bias() with -novb (hgaprec.cc:1276-1297): theta.update_rate_next(betasum), then
+    _theta.sum_rows() -- still the OLD expectations, nothing is swapped yet -- feeds
+    beta.update_rate_next; the default branch (1250-1272) swaps theta first.  The K-vector
+    rates after one iteration say which sums went in."""
+    from tests.util import make_problem
+    n, m, K = 120, 90, 4
+    rowptr, col, val = make_problem(n, m, 1500, 8)
+    runs = {}
+    for novb in (False, True):
+        M = orc.Model(n, m, K, False, True, False, novb=novb)
+        M.set_csr(rowptr, col, val)
+        M.initialize(8)
+        start_t, start_b = M.state("THETA_E").copy(), M.state("BETA_E").copy()
+        M.iterate(1)
+        runs[novb] = {w: M.state(w).copy() for w in ("THETA_RATE", "BETA_RATE", "THETA_E", "BETA_E", "UBIAS_RATE", "IBIAS_RATE")}
+    for novb in (False, True):
+        assert np.allclose(runs[novb]["THETA_RATE"], 0.3 + start_b.sum(0), rtol=1e-14)     # both: old sum_i E[beta]
+        assert np.allclose(runs[novb]["UBIAS_RATE"], 0.3 + m) and np.allclose(runs[novb]["IBIAS_RATE"], 0.3 + n)
+    assert np.allclose(runs[True]["BETA_RATE"], 0.3 + start_t.sum(0), rtol=1e-14)          # -novb: OLD sum_u E[theta]
+    assert np.allclose(runs[False]["BETA_RATE"], 0.3 + runs[False]["THETA_E"].sum(0), rtol=1e-14)   # default: the new one
+    assert np.array_equal(runs[True]["THETA_E"], runs[False]["THETA_E"])                   # theta's update is the same
+    # without -bias the flag is never read (vb(), hgaprec.cc:919-980)
+    outs = []
+    for novb in (False, True):
+        M = orc.Model(n, m, K, False, False, False, novb=novb)
+        M.set_csr(rowptr, col, val); M.initialize(8); M.iterate(2)
+        outs.append(M.state("BETA_E").copy())
+    assert np.array_equal(outs[0], outs[1])

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profiling recipe of a round, run ON the GPU box from the repo root:
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # Writes under gpurun_out/<tag>/ ; tools/summarize_profiles.py turns that into profiles/<tag>/.
 # Counters are collected in their own passes (--kernel-trace --pmc only), as the
 # MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -25,10 +25,11 @@ for v in base xcd; do
   rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/xcd_pmc_tcc_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_tcc_$v.log
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/xcd_pmc_fetch_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_fetch_$v.log
 done
-# 5. row stride rounded to a 128-byte line (K=100: 800 -> 896 bytes)
-HPF_LD_ROUND=16 $BENCH > $OUT/bench_ld16.json 2> $OUT/bench_ld16.log
-# 6. the other configs on one GPU
-python bench.py --config C4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.log
+# 5. phi-pass time against the size of the gathered matrix (L2 / Infinity Cache / HBM)
+bash tools/size_sweep.sh $OUT/size > $OUT/size_sweep.txt 2>&1
+# 6. the other configs on one GPU; C1 and C4 WITH their CPU baseline
+python bench.py --config C1 --steps 20 --warmup 5 > $OUT/bench_c1.json 2> $OUT/bench_c1.log
+python bench.py --config C4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.log
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --host-handover > $OUT/bench_c3_full_1gpu.json 2> $OUT/bench_c3_full_1gpu.log
 python bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_full_1gpu.json 2> $OUT/bench_c5_full_1gpu.log
 # 7. what one of 8 GPUs would hold of C3 (1.25M users x ALL 1M items, 1.25e8 nnz): the compute side of the 8-GPU estimate
