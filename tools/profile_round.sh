@@ -13,7 +13,7 @@ BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 # 1. per-kernel time, same command as the bench line next to it
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o c2 -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.log
 # 2. counters, one pass each
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
   name=$(echo $pmc | tr ' ' '_' | tr 'A-Z' 'a-z' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$name -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$name.log
 done

@@ -2,7 +2,7 @@
 """gpurun_out/<tag>/ (raw rocprofv3 output of tools/profile_round.sh) ->
 profiles/<tag>/ (the summaries that are committed) + profiles/traffic.json.
 
-  python tools/summarize_profiles.py r02
+  python tools/summarize_profiles.py r03
 """
 import csv
 import glob
@@ -34,21 +34,25 @@ def counter_means(d):
     for f in glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in out.items()}
+    return {k: {c: (sum(v) / len(v), len(v), max(v)) for c, v in cs.items()} for k, cs in out.items()}
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src, dst = ROOT / "gpurun_out" / tag, ROOT / "profiles" / tag
     dst.mkdir(parents=True, exist_ok=True)
     for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, dst / "kernel_stats.csv")
     for f in glob.glob(str(src / "stats" / "**" / "*domain_stats.csv"), recursive=True):
         shutil.copy(f, dst / "domain_stats.csv")
-    for f in src.glob("*.json"):
+    for f in list(src.glob("*.json")) + list(src.glob("*.txt")):
         shutil.copy(f, dst / f.name)
+    if (src / "size").is_dir():
+        (dst / "size").mkdir(exist_ok=True)
+        for f in (src / "size").glob("*.json"):
+            shutil.copy(f, dst / "size" / f.name)
     ours = ("phi_pass_kernel", "row_sweep", "combine_partials", "colsum_finalize", "radix_", "item_hist", "scan_",
-            "derive_w", "repack_", "colsum_partial")
+            "derive_w", "repack_", "colsum_partial", "prior_update", "materialize_es")
     rows = []
     traffic = {}
     passes = {p.name: counter_means(p) for p in src.glob("pmc_*") if p.is_dir()}
@@ -61,7 +65,7 @@ def main():
             continue
         cs = merged[k]
         row = {"kernel": k, "dispatches": max(v[1] for v in cs.values())}
-        for c, (mean, _) in sorted(cs.items()):
+        for c, (mean, _, _) in sorted(cs.items()):
             row[c] = round(mean, 1)
         if "TCC_HIT_sum" in cs and "TCC_MISS_sum" in cs:
             h_, m_ = cs["TCC_HIT_sum"][0], cs["TCC_MISS_sum"][0]
@@ -70,6 +74,9 @@ def main():
             row["wait_any_share"] = round(cs["SQ_WAIT_ANY"][0] / cs["SQ_WAVE_CYCLES"][0], 3)      # waves parked on s_waitcnt
             if "SQ_ACTIVE_INST_ANY" in cs:
                 row["issuing_share"] = round(cs["SQ_ACTIVE_INST_ANY"][0] / cs["SQ_WAVE_CYCLES"][0], 3)
+        if "TCC_EA0_RDREQ_LEVEL_sum" in cs and cs.get("TCC_EA0_RDREQ_sum", (0,))[0] > 0:
+            # mean number of L2 -> fabric read requests in flight per request issued = their mean latency, L2 clocks
+            row["ea_read_latency_clk"] = round(cs["TCC_EA0_RDREQ_LEVEL_sum"][0] / cs["TCC_EA0_RDREQ_sum"][0], 1)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # KiB counters; FETCH_SIZE counts 64 B per 128-B request on gfx950 => x2 (MI355X_MICROARCH.md, HBM)
             row["hbm_side_bytes"] = int((2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024)
@@ -84,6 +91,25 @@ def main():
             if "hbm_side_bytes" in r and "phi_pass_kernel" in r["kernel"]:
                 side = "phi_item" if r["kernel"].rstrip(">").endswith("1") else "phi_user"
                 traffic[f"C2:{side}"] = r["hbm_side_bytes"]
+    # calibration of the FETCH_SIZE x 2 correction on a kernel whose byte count is known:
+    # materialize_es_kernel reads the n x ld raw sums once (its largest dispatch is the user side)
+    bj = src / "bench_under_rocprof.json"
+    if "materialize_es_kernel" in merged and "FETCH_SIZE" in merged["materialize_es_kernel"] and bj.exists():
+        try:
+            d = json.loads(bj.read_text().strip().splitlines()[-1])
+            ld = d["work"]["phi_G"] * d["work"]["phi_R"] * d["work"]["phi_V"]
+            want = d["config"]["users_per_gpu"] * ld * 8
+            cs = merged["materialize_es_kernel"]
+            got = 2 * cs["FETCH_SIZE"][2] * 1024
+            cal = {"kernel": "materialize_es_kernel (user side, largest dispatch)", "bytes_read_by_construction": want,
+                   "2x_FETCH_SIZE_bytes": got, "ratio": round(got / want, 4)}
+            if "WRITE_SIZE" in cs:
+                cal["bytes_written_by_construction"] = 2 * want
+                cal["WRITE_SIZE_bytes"] = cs["WRITE_SIZE"][2] * 1024
+                cal["write_ratio"] = round(cs["WRITE_SIZE"][2] * 1024 / (2 * want), 4)
+            (dst / "fetch_size_calibration.json").write_text(json.dumps(cal, indent=1) + "\n")
+        except Exception as ex:
+            print("calibration skipped:", ex)
     # XCD probe
     xcd = {}
     for v in ("base", "xcd", "m2000"):
@@ -100,9 +126,16 @@ def main():
                         xcd.setdefault(v, {}).setdefault("pmc_" + side, {}).update({c: round(x[0], 1) for c, x in cs.items()})
     if xcd:
         (dst / "xcd_locality_probe.json").write_text(json.dumps(xcd, indent=1))
+    c3f = src / "bench_c3_full_1gpu.json"
+    if traffic and c3f.exists() and c3f.read_text().strip():
+        # the item pass where nothing it gathers is cache-resident (9 GB of user rows): algorithmic GB/s
+        d3 = json.loads(c3f.read_text().strip().splitlines()[-1])
+        pk = d3["roofline"]["per_kernel"]["phi_item"]
+        traffic["C3:phi_item_hbm_only_GBps"] = pk["GBps"]
     if traffic:
         traffic["kernels_sha"] = kernels_sha()
-        traffic["measured"] = f"profiles/{tag}/pmc_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, bench.py --steps 3 --warmup 1"
+        traffic["measured"] = (f"profiles/{tag}/pmc_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, bench.py --steps 3 "
+                               f"--warmup 1; hbm_only: profiles/{tag}/bench_c3_full_1gpu.json (whole C3 on one GPU, algorithmic bytes / time)")
         (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
     c3 = src / "bench_c3_full_1gpu.json"
     if c3.exists() and c3.read_text().strip():
