@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--w32", action="store_true",
                     help="EXPERIMENTAL storage mode: W kept in fp32 (arithmetic/accumulators fp64); "
                          "drifts out of the 1e-4 contract after ~30 iterations -- NOT the headline configuration")
+    ap.add_argument("--w48", action="store_true",
+                    help="OPT-IN storage mode: W kept in 48 bits per element (top 48 bits of the fp64 value; "
+                         "arithmetic/accumulators fp64), 25-30 %% shorter rows -- NOT the headline configuration")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
                          "single-GPU smoke test of the N>1 code path)")
@@ -211,7 +214,7 @@ def main():
     for k in ("n", "m", "nnz", "K"):
         if getattr(args, k):
             cfg[k] = getattr(args, k)
-    custom = args.scale != 1.0 or args.w32 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
+    custom = args.scale != 1.0 or args.w32 or args.w48 or any(getattr(args, k) for k in ("n", "m", "nnz", "K"))
     m, K = cfg["m"], cfg["K"]
 
     # ---- synthetic shard, generated on the GPU and left there
@@ -253,10 +256,11 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     log(f"[rank {rank}] generated users [{ua}, {ub}) x {m} items, nnz={nnz_loc} in {t_gen:.1f}s")
+    torch.cuda.empty_cache()             # the generator's temporaries go back to the driver: the library allocates with hipMalloc
 
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
             device=local_rank, stream=stream.cuda_stream, n_ranks=2 if (force_dist and world == 1) else world,
-            rank=rank, n_users_total=n_total, w_storage=1 if args.w32 else 0)
+            rank=rank, n_users_total=n_total, w_storage=1 if args.w32 else 2 if args.w48 else 0)
     xbuf = None
     if use_dist:
         xbuf = torch.zeros(D.exchange_count(), dtype=torch.float64, device=dev)
@@ -518,7 +522,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else "f64", "data": "synthetic",
+            "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else
+                     "f64 arithmetic, W stored in 48 bits (opt-in mode)" if args.w48 else "f64", "data": "synthetic",
             "config": {
                 "workload": workload,
                 "users_total": n_total, "users_per_gpu": n_loc, "items": m, "nnz_per_gpu": nnz_loc,
@@ -564,6 +569,32 @@ def main():
             out["compute_ms"] = {"max": max(comp), "min": min(comp)}
         if rccl is not None:
             out["rccl"] = rccl
+        if world == 1 and not custom and not force_dist and (n_loc + m) * wi["ld"] * 8 * 5 + nnz_loc * 12 < 0.4 * free_b:
+            # context, never `value`: the same workload with W stored in 48 bits (hpf_config.w_storage = 2,
+            # opt-in): the passes are bound by bytes per gathered row, this is what shorter rows buy
+            try:
+                D2 = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
+                         stream=stream.cuda_stream, w_storage=2)
+                D2.upload_csr_device(rowptr, col, val)
+                start_state(D2, n_loc, row0, ss)
+                D2.iterate(2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                D2.iterate(5)
+                torch.cuda.synchronize()
+                ms48 = (time.perf_counter() - t0) / 5 * 1e3
+                tm48 = D2.mean_timing(5)
+                w2 = D2.work_info()
+                D2.close()
+                out["w48_opt_in"] = {
+                    "what": "same workload, W stored as the top 48 bits of its fp64 value (w_storage = 2; arithmetic fp64); "
+                            "NOT the headline configuration: drift vs the fp64 oracle ~3e-11 after 5 sweeps, ~1e-6 after 150 "
+                            "(tests/w32_error_growth.py; contract 1e-4)",
+                    "value": nnz_loc / (ms48 * 1e-3), "ms_per_step": ms48,
+                    "kernels_ms": {k: round(v, 4) for k, v in tm48.items() if k.endswith("_ms")},
+                    "row_bytes": w2["phi_G"] * w2["phi_R"] * 16, "fp64_row_bytes": wi["ld"] * 8}
+            except Exception as ex:
+                out["w48_opt_in"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline and not force_dist:
             s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
             s_users = min(s_users, n_loc)
@@ -586,7 +617,7 @@ def main():
             rp1, c1, v1 = synth.generate_device(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
                                                 seed=cfg["seed"], device=dev, binary=cfg["binary"])
             D1 = Hpf(n_total, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
-                     stream=stream.cuda_stream, w_storage=1 if args.w32 else 0)
+                     stream=stream.cuda_stream, w_storage=1 if args.w32 else 2 if args.w48 else 0)
             D1.upload_csr_device(rp1, c1, v1)
             nnz1 = int(rp1[-1])
             del rp1, c1, v1

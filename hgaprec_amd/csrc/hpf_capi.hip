@@ -69,6 +69,8 @@ struct hpf_handle {
   hpf_config cfg;
   uint32_t K = 0, C = 0, ld = 0;
   bool w32 = false;                     // W stored as float (hpf_config.w_storage = 1)
+  bool w48 = false;                     // W stored in 48 bits per element (w_storage = 2): phiR = 16-byte loads per lane,
+  uint32_t f48_E = 0, f48_chunk = 0, f48_row = 0;   // elements / bytes per lane chunk, bytes per W row
   uint32_t *flags = nullptr;            // device word: bit 0 = a softmax denominator underflowed
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -267,23 +269,62 @@ bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint3
                 : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
-template <int G>
+template <int G, bool F48>
 bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR>), dim3(blocks), dim3(256), 0, st, a); return true;
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, F48>), dim3(blocks), dim3(256), 0, st, a); return true;
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
   if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
-bool launch_sweep(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+template <bool F48>
+bool launch_sweep_g(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_sweep_r<4>(R, a, blocks, st);
-    case 8:  return launch_sweep_r<8>(R, a, blocks, st);
-    case 16: return launch_sweep_r<16>(R, a, blocks, st);
-    case 32: return launch_sweep_r<32>(R, a, blocks, st);
-    case 64: return launch_sweep_r<64>(R, a, blocks, st);
+    case 4:  return launch_sweep_r<4, F48>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8, F48>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16, F48>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32, F48>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64, F48>(R, a, blocks, st);
+  }
+  return false;
+}
+bool launch_sweep(bool f48, int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+{
+  return f48 ? launch_sweep_g<true>(G, R, a, blocks, st) : launch_sweep_g<false>(G, R, a, blocks, st);
+}
+
+// w_storage = 2: G lanes per nonzero, L 16-byte loads per lane (phi_pass_f48_kernel)
+template <int G, int L>
+void launch_phi48_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  if (side & 1) hipLaunchKernelGGL((phi_pass_f48_kernel<G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else          hipLaunchKernelGGL((phi_pass_f48_kernel<G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
+}
+template <int G>
+bool launch_phi48_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (L) {
+    case 1: launch_phi48_t<G, 1>(side, a, blocks, st); return true;
+    case 2: launch_phi48_t<G, 2>(side, a, blocks, st); return true;
+    case 3: launch_phi48_t<G, 3>(side, a, blocks, st); return true;
+    case 4: launch_phi48_t<G, 4>(side, a, blocks, st); return true;
+    case 5: launch_phi48_t<G, 5>(side, a, blocks, st); return true;
+    case 6: launch_phi48_t<G, 6>(side, a, blocks, st); return true;
+    case 7: launch_phi48_t<G, 7>(side, a, blocks, st); return true;
+    case 8: launch_phi48_t<G, 8>(side, a, blocks, st); return true;
+  }
+  return false;
+}
+bool launch_phi48(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_phi48_l<4>(L, side, a, blocks, st);
+    case 8:  return launch_phi48_l<8>(L, side, a, blocks, st);
+    case 16: return launch_phi48_l<16>(L, side, a, blocks, st);
+    case 32: return launch_phi48_l<32>(L, side, a, blocks, st);
+    case 64: return launch_phi48_l<64>(L, side, a, blocks, st);
   }
   return false;
 }
@@ -704,8 +745,8 @@ int prepare_derived(hpf_handle *h)
     if (!s->rows || !s->w_dirty) continue;
     s->w_dirty = false;
     const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
-    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W, (uint32_t)h->w32,
-                       s->rows, h->ld, h->K, s->bias_col, s->junk_col);
+    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W, h->w48 ? 2u : (uint32_t)h->w32,
+                       s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->f48_E, h->f48_chunk, h->f48_row);
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
   {
@@ -740,7 +781,8 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
   if (a.nseg) {
     const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-    if (!launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream)) {
+    if (!(h->w48 ? launch_phi48(h->phiG, h->phiR, side, a, blocks, h->stream)
+                 : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream))) {
       h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
     }
   }
@@ -770,6 +812,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   SweepArgs a;
   a.S = s.S; a.W = s.W; a.w32 = h->w32;
+  a.f48_E = h->f48_E; a.f48_chunk = h->f48_chunk; a.f48_row = h->f48_row;
   s.l_stale = true; s.es_stale = true;
   a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
@@ -777,7 +820,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
+  if (!launch_sweep(h->w48, h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   if (h->cfg.hier && s.rows)                // xi / eta: E and Elog from the rate the sweep just wrote
@@ -971,7 +1014,8 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
   h->w32 = cfg->w_storage == 1;          // only ever chosen by the caller's hpf_config
-  if (cfg->w_storage > 1) { delete h; return HPF_ERR_INVALID; }
+  h->w48 = cfg->w_storage == 2;
+  if (cfg->w_storage > 2) { delete h; return HPF_ERR_INVALID; }
   h->K = cfg->K; h->C = C;
   // Tuning knobs are read from the environment ONLY under HPF_EXPERIMENTAL=1 (tests, tools/):
   // a stray variable must not change the layout or the summation order of a production run.
@@ -1022,14 +1066,34 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       }
     }
     h->ld = (uint32_t)(h->phiG * h->phiR * h->phiV);
+    if (h->w48) {
+      // 48-bit W: G lanes x L 16-byte loads; E = 8L/3 elements per lane chunk; fewest row bytes
+      // G*L*16 with G*E >= C, then the widest lane group (a 128-byte line per load from G = 8)
+      long bestb = -1; int bg = 0, bl = 0;
+      const int Gq[5] = {8, 16, 32, 64, 4};
+      for (int g : Gq)
+        for (int l = 1; l <= 8; ++l) {
+          const int e = (8 * l) / 3;
+          if ((uint32_t)(g * e) < C) continue;
+          const long b = (long)g * l * 16 + ((g == 4 && C * 6 >= 256) ? 64 : 0);      // narrow groups lose (K sweep of round 1)
+          if (bestb < 0 || b < bestb) { bestb = b; bg = g; bl = l; }
+          break;                                                                     // larger l only adds bytes
+        }
+      if (bestb < 0) return fail(HPF_ERR_UNSUPPORTED);
+      h->phiG = bg; h->phiR = bl; h->phiV = 0;
+      h->f48_E = (uint32_t)((8 * bl) / 3); h->f48_chunk = (uint32_t)bl * 16u; h->f48_row = (uint32_t)(bg * bl) * 16u;
+      h->ld = (uint32_t)bg * h->f48_E;
+    }
     // the row sweep gives G' lanes to a row with R' columns each, G'*R' == ld exactly
+    // (48-bit W: G'*R' >= ld, the excess columns of the last slots are masked)
     h->swG = h->swR = 0;
     const int Gs[5] = {64, 32, 16, 8, 4};
     int best = 1 << 30;
     for (int g : Gs) {
-      if (h->ld % (uint32_t)g) continue;
-      const int r = (int)(h->ld / (uint32_t)g);
+      if (!h->w48 && h->ld % (uint32_t)g) continue;
+      const int r = (int)((h->ld + (uint32_t)g - 1) / (uint32_t)g);
       if (r < 1 || r > (g == 64 ? 16 : 8)) continue;
+      if (h->w48 && (uint32_t)(g * r) - h->ld >= (uint32_t)g && r > 1) continue;
       const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (g * 8 < 128 ? 1 : 0);   // same preferences as round 1's K sweep
       if (p < best || (p == best && g < h->swG)) { best = p; h->swG = g; h->swR = r; }
     }
@@ -1530,7 +1594,7 @@ void fill_snap_header(hpf_handle *h, SnapHeader *hd)
   memset(hd, 0, sizeof *hd);
   memcpy(hd->magic, "HPFSNAP2", 8);
   hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
-  hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->w32; hd->iterations = h->iterations;
+  hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->cfg.w_storage; hd->iterations = h->iterations;
   hd->n_users_total = h->cfg.n_users_total; hd->rank = h->cfg.rank; hd->n_ranks = h->cfg.n_ranks;
   hd->novb = h->jacobi ? 1u : 0u; hd->nnz = h->have_csr ? h->nnz : 0;
   hd->s_prior = h->cfg.s_prior; hd->r_prior = h->cfg.r_prior;
@@ -1580,7 +1644,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
   // ---- everything is validated before the handle is touched: a rejected blob leaves it as it was
   SnapHeader hd; memcpy(&hd, host, sizeof hd);
   if (memcmp(hd.magic, "HPFSNAP2", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
-      hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (uint32_t)h->w32) {
+      hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != h->cfg.w_storage) {
     h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
   }
   if (hd.s_prior != h->cfg.s_prior || hd.r_prior != h->cfg.r_prior || hd.n_users_total != h->cfg.n_users_total ||
@@ -1732,7 +1796,7 @@ int hpf_elbo(hpf_handle *h, double *out)
   do {
     // fp64 W: logsumexp from the hot loop's W and the row maxima of Elog (no exp per
     // element); the f32-stored W is not precise enough for that, it takes the Elog form
-    const bool from_w = !h->w32 && h->nnz;
+    const bool from_w = !h->w32 && !h->w48 && h->nnz;
     if (from_w) {
       if ((rc = prepare_derived(h))) break;                  // W follows a set_state(ELOG), if any
       if ((rc = dalloc(h, &Mt, h->u.rows)) || (rc = dalloc(h, &Mb, h->it.rows))) break;
@@ -1991,7 +2055,7 @@ int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item,
   // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
   const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
   const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
-  const uint64_t se = h->w32 ? 4 : 8, sa = 8;        // bytes per stored W element / per accumulator
+  const uint64_t se = h->w32 ? 4 : h->w48 ? 6 : 8, sa = 8;        // bytes per stored W element / per accumulator
   if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * se + n * Kp * (se + sa);
   if (phi_item) *phi_item = nnz * Kp * se;
   if (rows) *rows = (n + m) * Kp * (2 * sa + 2 * se) + 64 * (n + m);

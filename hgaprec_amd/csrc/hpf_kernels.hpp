@@ -258,6 +258,174 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
+// ---------------------------------------------------------------------
+// K1 with W stored in 48 bits per element (hpf_config.w_storage = 2, opt-in).
+// Both phi passes sit at the rate at which L2 misses are filled: the only
+// lever left is bytes per gathered row.  "f48" keeps the TOP 48 BITS of each fp64 W
+// (sign, 11 exponent bits, 36 mantissa bits; rounded to nearest even by the sweep: relative
+// error <= 2^-37 = 7.3e-12) -- K = 100 rows take five 128-byte lines instead of seven.
+// Arithmetic and accumulators stay fp64.
+//
+// Row layout: G lane chunks of L*16 bytes.  Chunk g holds columns g*E .. g*E + E - 1,
+// E = (8 L) / 3: first the E high dwords, then the E 16-bit low parts packed two per dword.
+// Lane g of a group loads its chunk with L 16-byte loads; element e decodes with one shift
+// or mask:  bits = hi[e] << 32 | lo16[e] << 16.  Row stride of the fp64 matrices (S, E, Elog)
+// and of the exchange buffer: ld = G*E columns, lane g owning the same E columns.
+// ---------------------------------------------------------------------
+template <int L> struct f48 {
+  static constexpr int E = (8 * L) / 3;                   // elements per lane chunk: 2 5 8 10 13 16 18 21
+  static_assert(E + (E + 1) / 2 <= 4 * L, "chunk overflow");
+};
+
+__device__ __forceinline__ void f48_encode(double w, uint32_t *hi, uint16_t *lo)
+{
+  unsigned long long b = (unsigned long long)__double_as_longlong(w);
+  b += 0x7fffull + ((b >> 16) & 1ull);                    // round to nearest even at bit 16
+  *hi = (uint32_t)(b >> 32); *lo = (uint16_t)(b >> 16);
+}
+
+// store column c of a row in the f48 layout (sweep, derive_w): E elements per 16*L-byte chunk
+__device__ __forceinline__ void f48_store(void *W, size_t row, uint32_t c, uint32_t E, uint32_t chunk_bytes,
+                                          uint32_t row_bytes, double w)
+{
+  uint32_t hi; uint16_t lo;
+  f48_encode(w, &hi, &lo);
+  unsigned char *p = (unsigned char *)W + row * (size_t)row_bytes + (size_t)(c / E) * chunk_bytes;
+  const uint32_t e = c % E;
+  ((uint32_t *)p)[e] = hi;
+  ((uint16_t *)(p + 4 * E))[e] = lo;
+}
+
+template <int L>
+struct f48_raw { uint4 q[L]; };
+
+template <int L>
+__device__ __forceinline__ double f48_get(const f48_raw<L> &r, int e)
+{
+  constexpr int E = f48<L>::E;
+  auto dw = [&](int k) -> uint32_t {
+    const uint4 &v = r.q[k / 4];
+    return (k % 4) == 0 ? v.x : (k % 4) == 1 ? v.y : (k % 4) == 2 ? v.z : v.w;
+  };
+  const uint32_t hi = dw(e);
+  const uint32_t lw = dw(E + e / 2);
+  const uint32_t lo = (e & 1) ? (lw & 0xffff0000u) : (lw << 16);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+template <int G, int L>
+__device__ __forceinline__ void phi_batch_f48(const f48_raw<L> &x, const double (&own)[f48<L>::E],
+                                              double (&acc)[f48<L>::E], float yf, bool &underflow)
+{
+  constexpr int E = f48<L>::E;
+  double xv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) xv[e] = f48_get<L>(x, e);
+  double s[2] = {0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e & 1] = (e < 2) ? own[e] * xv[e] : fma(own[e], xv[e], s[e & 1]);
+  const double ssum = group_sum<G>((E > 1) ? s[0] + s[1] : s[0]);
+  const double yy = (double)yf;
+  const bool ok = ssum > 0.0;
+  underflow |= (yf > 0.0f) && !ok;
+  const double scale = ok ? yy * fast_rcp(ssum) : 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = fma(xv[e], scale, acc[e]);
+}
+
+template <int G, int L, int SIDE>
+__global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
+{
+  constexpr int NG = 64 / G;
+  constexpr int E = f48<L>::E;
+  constexpr uint32_t LD = G * E;                 // columns: stride of S / partial
+  constexpr uint32_t ROWB = G * L * 16;          // bytes of a W row
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G, q = lane / G;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * (L * 16);
+  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * (L * 16);
+  bool underflow = false;
+
+  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+    const Seg sg = a.segs[s];
+    const uint32_t len = sg.len;
+    const int64_t start = sg.start;
+    double own[E], acc[E];
+    {
+      f48_raw<L> r;
+      const uint4 *wo = reinterpret_cast<const uint4 *>(W_own + (size_t)sg.row * ROWB);
+#pragma unroll
+      for (int t = 0; t < L; ++t) r.q[t] = wo[t];
+#pragma unroll
+      for (int e = 0; e < E; ++e) { own[e] = f48_get<L>(r, e); acc[e] = 0.0; }
+    }
+    if (len > 0) {
+      auto load_i = [&](uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
+      auto load_y = [&](uint32_t o) -> float {
+        if (o >= len) return 0.0f;
+        if (!a.val) return 1.0f;
+        const uint32_t y = a.val[start + o];
+        return (y > 1u) ? (float)y : 1.0f;
+      };
+      uint32_t cur_i = load_i((uint32_t)lane), nxt_i = load_i(64u + lane);
+      float cur_y = load_y((uint32_t)lane), nxt_y = load_y(64u + lane);
+      const uint32_t nb = (len + NG - 1) / NG;
+      f48_raw<L> xa, xb;
+      float ya, yb = 0.0f;
+      auto gather = [&](f48_raw<L> &x, float &y, uint32_t b) {
+        const int src = (int)((b % G) * NG) + q;
+        const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
+        y = __shfl(cur_y, src, 64);
+        const uint4 *p = reinterpret_cast<const uint4 *>(W_oth + (size_t)in * ROWB);
+#pragma unroll
+        for (int t = 0; t < L; ++t) x.q[t] = p[t];
+      };
+      auto next_chunk = [&](uint32_t b) {
+        cur_i = nxt_i; cur_y = nxt_y;
+        const uint32_t o = (b / G + 1) * 64u + lane;
+        nxt_i = load_i(o); nxt_y = load_y(o);
+      };
+      // same schedule as phi_pass_kernel: two register sets, peeled tail
+      gather(xa, ya, 0);
+      if (nb > 1) gather(xb, yb, 1);
+      uint32_t bb = 0;
+      for (; bb + 3 < nb; bb += 2) {
+        phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+        __builtin_amdgcn_sched_barrier(0);
+        if (((bb + 2) % G) == 0) next_chunk(bb + 2);
+        gather(xa, ya, bb + 2);
+        phi_batch_f48<G, L>(xb, own, acc, yb, underflow);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(xb, yb, bb + 3);
+      }
+      phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+      if (bb + 1 < nb) {
+        const bool third = bb + 2 < nb;
+        __builtin_amdgcn_sched_barrier(0);
+        if (third) {
+          if (((bb + 2) % G) == 0) next_chunk(bb + 2);
+          gather(xa, ya, bb + 2);
+        }
+        phi_batch_f48<G, L>(xb, own, acc, yb, underflow);
+        if (third) phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+      }
+    }
+    double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + (size_t)g * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      double r = acc[e];
+      if (G <= 32) r += __shfl_xor(r, 32, 64);
+      if (G <= 16) r += __shfl_xor(r, 16, 64);
+      if (G <= 8)  r += __shfl_xor(r, 8, 64);
+      if (G <= 4)  r += __shfl_xor(r, 4, 64);
+      if (q == 0) dst[e] = own[e] * r;
+    }
+  }
+  if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
+}
+
 // long rows: S[row] = sum over its segments' partials, in segment order.
 // One wave per long row; a lane owns columns c and c + 64 at once and the slot
 // loop is unrolled 16-fold, so 32 independent loads are in flight per lane
@@ -403,6 +571,7 @@ struct SweepArgs {
   const double *colsum_oth; // [ld]   sum over the other side's rows of E
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
+  uint32_t      f48_E, f48_chunk, f48_row;   // w_storage = 2: elements and bytes per lane chunk, bytes per W row
   int32_t       bias_col;   // column holding this side's bias (-1: none)
   int32_t       junk_col;   // column holding the other side's bias (-1: none)
   double        bias_rate_add;  // n_other_total for the bias column
@@ -410,10 +579,14 @@ struct SweepArgs {
   uint32_t      hier;
 };
 
-template <int G, int R>
+// F48 = false: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no
+// column test.  F48 = true (w_storage = 2): the stride a.ld = G_phi * E may be smaller than G*R; the
+// slots from tb on then also hold columns past the end of the row, whose loads and stores are
+// masked, and W goes out in the 48-bit layout of phi_pass_f48_kernel.
+template <int G, int R, bool F48>
 __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 {
-  constexpr uint32_t LD = G * R;         // the row stride IS G*R (hpf_create): no column test
+  const uint32_t LD = F48 ? a.ld : (uint32_t)(G * R);
   __shared__ double red[4][G * R];       // per-wave column partials
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane % G, q = lane / G;
@@ -444,7 +617,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
   double snx[R]; double prn = a.r_prior;
   if (grp < a.rows) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) snx[t] = a.S[(size_t)grp * LD + g + G * t];
+    for (int t = 0; t < R; ++t) snx[t] = (!F48 || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)grp * LD + g + G * t] : 0.0;
     if (hier) prn = a.prior_E[grp];
   }
   for (uint32_t row = grp; row < a.rows; row += ngrp) {
@@ -456,7 +629,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     const uint32_t nr = row + ngrp;
     if (nr < a.rows) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) snx[t] = a.S[(size_t)nr * LD + g + G * t];
+      for (int t = 0; t < R; ++t) snx[t] = (!F48 || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)nr * LD + g + G * t] : 0.0;
       if (hier) prn = a.prior_E[nr];
     }
     double wmax = 0.0, rsum = 0.0;
@@ -486,7 +659,11 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     wmax = group_max<G>(wmax);
     rsum = group_sum<G>(rsum);
     const double inv = (wmax > 0.0) ? fast_rcp(wmax) : 0.0;
-    if (a.w32) {
+    if (F48) {
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if ((uint32_t)(g + G * t) < LD) f48_store(a.W, row, g + G * t, a.f48_E, a.f48_chunk, a.f48_row, w[t] * inv);
+    } else if (a.w32) {
 #pragma unroll
       for (int t = 0; t < R; ++t) ((float *)a.W)[base + g + G * t] = (float)(w[t] * inv);
     } else {
@@ -615,9 +792,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
 }
 
 // W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
-__global__ void derive_w_kernel(const double *L, void *W, uint32_t w32, uint32_t rows,
+// wmode: 0 double, 1 float, 2 the 48-bit layout (f48_E elements per f48_chunk-byte lane chunk)
+__global__ void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32_t rows,
                                 uint32_t ld, uint32_t K, int32_t bias_col,
-                                int32_t junk_col)
+                                int32_t junk_col, uint32_t f48_E, uint32_t f48_chunk, uint32_t f48_row)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -632,7 +810,8 @@ __global__ void derive_w_kernel(const double *L, void *W, uint32_t w32, uint32_t
     for (uint32_t c = lane; c < ld; c += 64) {
       const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
       const double wv = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
-      if (w32) ((float *)W)[(size_t)row * ld + c] = (float)wv;
+      if (wmode == 2) f48_store(W, row, c, f48_E, f48_chunk, f48_row, wv);
+      else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
       else ((double *)W)[(size_t)row * ld + c] = wv;
     }
   }

@@ -82,11 +82,18 @@ typedef struct {
   int32_t  device;         /* HIP device ordinal                             */
   uint32_t n_ranks;        /* 1 => hpf_iterate() needs no exchange           */
   uint32_t rank;
-  uint32_t w_storage;      /* 0: W = exp(Elog - rowmax) stored fp64 (default).   */
-                           /* 1: EXPERIMENTAL, stored fp32 (gathers halve, 1.4x   */
-                           /*    faster at C2) -- measured to drift out of the    */
-                           /*    1e-4 parity contract after ~30 iterations; see   */
-                           /*    DESIGN.md.  Never selected implicitly.           */
+  uint32_t w_storage;      /* how W = exp(Elog - rowmax), the matrix the phi      */
+                           /* passes gather, is stored (arithmetic and             */
+                           /* accumulators are fp64 in every mode):                */
+                           /* 0: fp64 (default; the only mode chosen implicitly).  */
+                           /* 1: EXPERIMENTAL fp32 -- drifts out of the 1e-4       */
+                           /*    parity contract after ~30 iterations. */
+                           /* 2: OPT-IN 48 bits: the top 48 bits of the fp64 value */
+                           /*    (36 mantissa bits, rounded to nearest even); rows */
+                           /*    are 25-30 % shorter, both phi passes faster by    */
+                           /*    about that; measured drift vs the fp64 oracle     */
+                           /*    ~1e-11 per early sweep, inside 1e-4 after         */
+                           /*    hundreds (tests/w32_error_growth.py).             */
   void    *stream;         /* hipStream_t to run on, NULL => own stream      */
   double   s_prior;        /* 0.3 (hgaprec.cc:13-20 hard-codes both)         */
   double   r_prior;        /* 0.3                                            */

@@ -509,6 +509,43 @@ def test_f32_stored_w_experimental_mode(orc, K, hier, bias):
     assert et > 1e-12                                   # it really is a different storage precision
 
 
+@pytest.mark.parametrize("K,hier,bias,binary", [(5, True, False, False), (20, True, True, False), (100, True, False, False),
+                                                (102, True, True, False), (50, False, True, True), (7, False, False, False)])
+def test_48_bit_stored_w_opt_in_mode(orc, K, hier, bias, binary):
+    """Opt-in storage mode hpf_config.w_storage = 2 (never the default): W keeps the top 48 bits of
+    its fp64 value (36 mantissa bits, rounded to nearest even: 2^-37 relative), rows are 25-30 %
+    shorter, arithmetic and accumulators stay fp64.  Its rounding is 8 000 times finer than the f32
+    mode's and is amplified by the CAVI map the same way (tests/w32_error_growth.py): ~1e-11 per
+    sweep early on, inside the 1e-4 contract after hundreds of sweeps."""
+    outs = []
+    for rep in range(2):
+        M, D = _run_pair(orc, 400, 300, K, 12000, hier, bias, binary, 6, seed=5, w_storage=2)
+        wi = D.work_info()
+        D.iterate(6)
+        outs.append([D.get_state(w) for w in compare_states(hier, bias)])
+    M.iterate(6)
+    assert wi["ld"] >= K + (2 if bias else 0) and wi["phi_V"] == 0            # the 48-bit kernel shape
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))                   # deterministic
+    worst = 0.0
+    for w, a in zip(compare_states(hier, bias), outs[0]):
+        e = rel_err(a, M.state(w))
+        assert e < 1e-7, (w, e)              # three orders inside the contract (Elog entries near zero weigh most)
+        worst = max(worst, e)
+    hu, hi, hy = heldout_pairs(400, 300, 500, seed=5)
+    assert abs(D.heldout_ll(hu, hi, hy)[0] - M.heldout_sum(hu, hi, hy)) / hu.size < 1e-8
+    assert abs(D.elbo() - M.elbo()) <= 1e-8 * abs(M.elbo())
+    if K >= 20:
+        assert worst > 1e-13                                                  # it really is a different storage precision
+
+
+def test_48_bit_stored_w_stays_inside_the_contract_over_a_long_run(orc):
+    M, D = _run_pair(orc, 400, 300, 50, 12000, True, True, False, 150, seed=5, w_storage=2)
+    M.iterate(150)
+    D.iterate(150)
+    for w in ("THETA_E", "BETA_E", "XI_E", "ETA_E", "UBIAS_E", "IBIAS_E"):
+        assert rel_err(D.get_state(w), M.state(w)) < 1e-4, w           # north_star's tolerance
+
+
 def test_fp64_drift_stays_tiny_over_many_sweeps(orc):
     # the default path against the oracle after 150 sweeps (contract: 1e-4)
     M, D = _run_pair(orc, 400, 300, 50, 12000, True, True, False, 150, seed=5)

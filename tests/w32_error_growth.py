@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""How far the f32-stored-W mode drifts from the fp64 CPU oracle as iterations go by."""
+"""How far the compact W storage modes (f32: w_storage = 1, 48-bit: w_storage = 2) drift from the
+fp64 CPU oracle as iterations go by, next to the default fp64 storage."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -12,7 +13,7 @@ for K, hier, bias in ((5, True, False), (21, True, True), (100, True, False), (5
     n, m = 400, 300
     rowptr, col, val = make_problem(n, m, 12000, 5)
     M = orc.Model(n, m, K, hier, bias, False); M.set_csr(rowptr, col, val); M.initialize(5)
-    D = {ws: Hpf(n, m, K, hier=hier, bias=bias, w_storage=ws) for ws in (0, 1)}
+    D = {ws: Hpf(n, m, K, hier=hier, bias=bias, w_storage=ws) for ws in (0, 1, 2)}
     for d in D.values():
         d.upload_csr(rowptr, col, val); copy_state(M, d, hier, bias)
     out = []
@@ -23,5 +24,5 @@ for K, hier, bias in ((5, True, False), (21, True, True), (100, True, False), (5
             d.iterate(upto - done)
         done = upto
         te, be = M.state("THETA_E"), M.state("BETA_E")
-        out.append((upto,) + tuple(max(rel_err(D[ws].get_state("THETA_E"), te), rel_err(D[ws].get_state("BETA_E"), be)) for ws in (0, 1)))
-    print(f"K={K} hier={hier} bias={bias}: " + "  ".join(f"it{u}: f64 {a:.1e} f32W {b:.1e}" for u, a, b in out), flush=True)
+        out.append((upto,) + tuple(max(rel_err(D[ws].get_state("THETA_E"), te), rel_err(D[ws].get_state("BETA_E"), be)) for ws in (0, 1, 2)))
+    print(f"K={K} hier={hier} bias={bias}: " + "  ".join(f"it{u}: f64 {a:.1e} f32W {b:.1e} f48W {c:.1e}" for u, a, b, c in out), flush=True)
