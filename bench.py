@@ -547,12 +547,16 @@ def main():
                 "hbm_only_source": hbm_only_note if hbm_only else "no DRAM-side counter in rocprofv3 -L on gfx950; "
                                    "no whole-C3 profile of this kernel source in profiles/traffic.json",
                 "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
+                # rows of W as stored: plain fp64 (8 B per element) or the LOSSLESS 59-bit packing the
+                # library picks where it saves a 128-byte line per row; the algorithmic bytes above
+                # use the stored element size, so they never exceed what has to move
+                "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)"}.get(wi["w_layout"]),
                 "hbm_copy_measured_GBps": copy_gbs,
                 "per_kernel": per_kernel,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
             "work": {k: wi[k] for k in ("user_segments", "item_segments", "user_long_rows", "item_long_rows",
-                                        "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R")},
+                                        "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R", "ld", "w_layout")},
             "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
             # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user
@@ -592,7 +596,8 @@ def main():
                             "(tests/w32_error_growth.py; contract 1e-4)",
                     "value": nnz_loc / (ms48 * 1e-3), "ms_per_step": ms48,
                     "kernels_ms": {k: round(v, 4) for k, v in tm48.items() if k.endswith("_ms")},
-                    "row_bytes": w2["phi_G"] * w2["phi_R"] * 16, "fp64_row_bytes": wi["ld"] * 8}
+                    "row_bytes": w2["phi_G"] * w2["phi_R"] * 16,
+                    "default_row_bytes": wi["phi_G"] * wi["phi_R"] * (16 if wi["w_layout"] else 8 * wi["phi_V"])}
             except Exception as ex:
                 out["w48_opt_in"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline and not force_dist:

@@ -70,7 +70,7 @@ class HpfWorkInfo(C.Structure):
         ("item_segments", C.c_uint32), ("item_long_rows", C.c_uint32), ("item_huge_rows", C.c_uint32),
         ("phi_G", C.c_uint32), ("phi_R", C.c_uint32), ("phi_V", C.c_uint32),
         ("sweep_G", C.c_uint32), ("sweep_R", C.c_uint32), ("ld", C.c_uint32),
-        ("graph_replay", C.c_uint32), ("reserved", C.c_uint32 * 3),
+        ("graph_replay", C.c_uint32), ("w_layout", C.c_uint32), ("reserved", C.c_uint32 * 2),
     ]
 
 

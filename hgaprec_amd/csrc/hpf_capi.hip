@@ -69,8 +69,9 @@ struct hpf_handle {
   hpf_config cfg;
   uint32_t K = 0, C = 0, ld = 0;
   bool w32 = false;                     // W stored as float (hpf_config.w_storage = 1)
-  bool w48 = false;                     // W stored in 48 bits per element (w_storage = 2): phiR = 16-byte loads per lane,
-  uint32_t f48_E = 0, f48_chunk = 0, f48_row = 0;   // elements / bytes per lane chunk, bytes per W row
+  int wl = WL_PLAIN;                    // layout of W rows: plain, WL_P59 (lossless packing, default where it shortens
+                                        // the row) or WL_F48 (w_storage = 2); packed: phiR = 16-byte pieces per lane
+  PackedRow pk = {0, 0, 0, 0};
   uint32_t *flags = nullptr;            // device word: bit 0 = a softmax denominator underflowed
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -269,64 +270,70 @@ bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint3
                 : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
-template <int G, bool F48>
+template <int G, int WL>
 bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, F48>), dim3(blocks), dim3(256), 0, st, a); return true;
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, WL>), dim3(blocks), dim3(256), 0, st, a); return true;
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
   if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
-template <bool F48>
+template <int WL>
 bool launch_sweep_g(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_sweep_r<4, F48>(R, a, blocks, st);
-    case 8:  return launch_sweep_r<8, F48>(R, a, blocks, st);
-    case 16: return launch_sweep_r<16, F48>(R, a, blocks, st);
-    case 32: return launch_sweep_r<32, F48>(R, a, blocks, st);
-    case 64: return launch_sweep_r<64, F48>(R, a, blocks, st);
+    case 4:  return launch_sweep_r<4, WL>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8, WL>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16, WL>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32, WL>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64, WL>(R, a, blocks, st);
   }
   return false;
 }
-bool launch_sweep(bool f48, int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_sweep(int wl, int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-  return f48 ? launch_sweep_g<true>(G, R, a, blocks, st) : launch_sweep_g<false>(G, R, a, blocks, st);
+  return wl == WL_P59 ? launch_sweep_g<WL_P59>(G, R, a, blocks, st)
+       : wl == WL_F48 ? launch_sweep_g<WL_F48>(G, R, a, blocks, st) : launch_sweep_g<WL_PLAIN>(G, R, a, blocks, st);
 }
 
-// w_storage = 2: G lanes per nonzero, L 16-byte loads per lane (phi_pass_f48_kernel)
-template <int G, int L>
-void launch_phi48_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+// packed W rows: G lanes per nonzero, L 16-byte pieces per lane (phi_pass_packed_kernel)
+template <template <int> class C, int G, int L>
+void launch_phipk_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  if (side & 1) hipLaunchKernelGGL((phi_pass_f48_kernel<G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
-  else          hipLaunchKernelGGL((phi_pass_f48_kernel<G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
+  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
 }
-template <int G>
-bool launch_phi48_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+template <template <int> class C, int G>
+bool launch_phipk_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (L) {
-    case 1: launch_phi48_t<G, 1>(side, a, blocks, st); return true;
-    case 2: launch_phi48_t<G, 2>(side, a, blocks, st); return true;
-    case 3: launch_phi48_t<G, 3>(side, a, blocks, st); return true;
-    case 4: launch_phi48_t<G, 4>(side, a, blocks, st); return true;
-    case 5: launch_phi48_t<G, 5>(side, a, blocks, st); return true;
-    case 6: launch_phi48_t<G, 6>(side, a, blocks, st); return true;
-    case 7: launch_phi48_t<G, 7>(side, a, blocks, st); return true;
-    case 8: launch_phi48_t<G, 8>(side, a, blocks, st); return true;
+    case 1: launch_phipk_t<C, G, 1>(side, a, blocks, st); return true;
+    case 2: launch_phipk_t<C, G, 2>(side, a, blocks, st); return true;
+    case 3: launch_phipk_t<C, G, 3>(side, a, blocks, st); return true;
+    case 4: launch_phipk_t<C, G, 4>(side, a, blocks, st); return true;
+    case 5: launch_phipk_t<C, G, 5>(side, a, blocks, st); return true;
+    case 6: launch_phipk_t<C, G, 6>(side, a, blocks, st); return true;
+    case 7: launch_phipk_t<C, G, 7>(side, a, blocks, st); return true;
+    case 8: launch_phipk_t<C, G, 8>(side, a, blocks, st); return true;
   }
   return false;
 }
-bool launch_phi48(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+template <template <int> class C>
+bool launch_phipk_g(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_phi48_l<4>(L, side, a, blocks, st);
-    case 8:  return launch_phi48_l<8>(L, side, a, blocks, st);
-    case 16: return launch_phi48_l<16>(L, side, a, blocks, st);
-    case 32: return launch_phi48_l<32>(L, side, a, blocks, st);
-    case 64: return launch_phi48_l<64>(L, side, a, blocks, st);
+    case 4:  return launch_phipk_l<C, 4>(L, side, a, blocks, st);
+    case 8:  return launch_phipk_l<C, 8>(L, side, a, blocks, st);
+    case 16: return launch_phipk_l<C, 16>(L, side, a, blocks, st);
+    case 32: return launch_phipk_l<C, 32>(L, side, a, blocks, st);
+    case 64: return launch_phipk_l<C, 64>(L, side, a, blocks, st);
   }
   return false;
+}
+bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, blocks, st) : launch_phipk_g<codec_f48>(G, L, side, a, blocks, st);
 }
 
 // surfaces a numerical breakdown the kernels flagged (synchronises the stream)
@@ -335,6 +342,11 @@ int check_flags(hpf_handle *h)
   uint32_t f = 0;
   HIPCHK(h, hipMemcpyAsync(&f, h->flags, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (f & 2u) {
+    h->err = "an entry of W fell below 2^-127 of its row maximum (Elog spread > 88 inside a row): the packed row layout "
+             "cannot hold it; create the handle with w_storage = 3 (plain fp64 rows)";
+    return HPF_ERR_STATE;
+  }
   if (f & 1u) {
     h->err = h->w32 ? "a softmax denominator underflowed to zero: the Elog spread is too wide for f32-stored W; use w_storage = 0"
                     : "a softmax denominator underflowed to zero (Elog spread > ~700): the state is not a valid HPF state";
@@ -745,8 +757,9 @@ int prepare_derived(hpf_handle *h)
     if (!s->rows || !s->w_dirty) continue;
     s->w_dirty = false;
     const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
-    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W, h->w48 ? 2u : (uint32_t)h->w32,
-                       s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->f48_E, h->f48_chunk, h->f48_row);
+    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
+                       h->wl != WL_PLAIN ? (uint32_t)h->wl : (uint32_t)h->w32,
+                       s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->pk, h->flags);
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
   {
@@ -781,7 +794,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
   if (a.nseg) {
     const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-    if (!(h->w48 ? launch_phi48(h->phiG, h->phiR, side, a, blocks, h->stream)
+    if (!(h->wl != WL_PLAIN ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
                  : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream))) {
       h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
     }
@@ -812,7 +825,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
   SweepArgs a;
   a.S = s.S; a.W = s.W; a.w32 = h->w32;
-  a.f48_E = h->f48_E; a.f48_chunk = h->f48_chunk; a.f48_row = h->f48_row;
+  a.pk = h->pk; a.flags = h->flags;
   s.l_stale = true; s.es_stale = true;
   a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
@@ -820,7 +833,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->w48, h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
+  if (!launch_sweep(h->wl, h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   if (h->cfg.hier && s.rows)                // xi / eta: E and Elog from the rate the sweep just wrote
@@ -1014,8 +1027,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
   h->w32 = cfg->w_storage == 1;          // only ever chosen by the caller's hpf_config
-  h->w48 = cfg->w_storage == 2;
-  if (cfg->w_storage > 2) { delete h; return HPF_ERR_INVALID; }
+  if (cfg->w_storage > 3) { delete h; return HPF_ERR_INVALID; }
   h->K = cfg->K; h->C = C;
   // Tuning knobs are read from the environment ONLY under HPF_EXPERIMENTAL=1 (tests, tools/):
   // a stray variable must not change the layout or the summation order of a production run.
@@ -1042,6 +1054,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   {
     // 16-byte loads when they pad no worse than 8-byte ones (measured: C2
     // phi_user 4.36 ms vs 4.52 ms).  Elements per load: doubles 1|2, floats 2|4.
+    bool phi_cfg_forced = false;
     const int Vs = h->w32 ? 2 : 1, Vl = 2 * Vs;
     int g1 = 0, r1 = 0, g2 = 0, r2 = 0;
     long w1 = 1L << 40, w2 = 1L << 40;
@@ -1063,26 +1076,40 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       if (sscanf(e, "%d,%d,%d", &g, &r, &v) == 3 && (h->w32 ? (v == 2 || v == 4) : (v == 1 || v == 2)) && r >= 1 && r <= 8 &&
           (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) && (uint32_t)(g * r * v) >= C && g * r * v <= 2048) {
         h->phiG = g; h->phiR = r; h->phiV = v;
+        phi_cfg_forced = true;                             // an explicit plain shape: no packing
       }
     }
     h->ld = (uint32_t)(h->phiG * h->phiR * h->phiV);
-    if (h->w48) {
-      // 48-bit W: G lanes x L 16-byte loads; E = 8L/3 elements per lane chunk; fewest row bytes
-      // G*L*16 with G*E >= C, then the widest lane group (a 128-byte line per load from G = 8)
-      long bestb = -1; int bg = 0, bl = 0;
-      const int Gq[5] = {8, 16, 32, 64, 4};
-      for (int g : Gq)
-        for (int l = 1; l <= 8; ++l) {
-          const int e = (8 * l) / 3;
-          if ((uint32_t)(g * e) < C) continue;
-          const long b = (long)g * l * 16 + ((g == 4 && C * 6 >= 256) ? 64 : 0);      // narrow groups lose (K sweep of round 1)
-          if (bestb < 0 || b < bestb) { bestb = b; bg = g; bl = l; }
-          break;                                                                     // larger l only adds bytes
+    {
+      // Packed rows: G lanes x L 16-byte pieces, E elements per lane (p59: 128L/59, f48: 8L/3); fewest
+      // row bytes G*L*16 with G*E >= C.  w_storage 0 takes the lossless p59 packing when it saves
+      // at least one 128-byte line per row against the plain fp64 row (K = 100: 6 instead of 7,
+      // K = 50: 3 instead of 4 -- measured on a C5 shard: 65.6 -> 51.7 ms); 2 asks for f48; 3 keeps
+      // plain rows.  HPF_W_PACK=1 (experimental) packs whenever a shape exists.
+      const bool force_pack = knob("HPF_W_PACK") && atoi(knob("HPF_W_PACK")) == 1;
+      const int want = cfg->w_storage == 2 ? WL_F48 : (cfg->w_storage == 0 || force_pack) && cfg->w_storage != 1 && cfg->w_storage != 3 ? WL_P59 : WL_PLAIN;
+      if (want != WL_PLAIN && !(phi_cfg_forced && want == WL_P59)) {
+        long bestb = -1; int bg = 0, bl = 0;
+        const int Gq[5] = {8, 16, 32, 64, 4};
+        for (int g : Gq)
+          for (int l = 1; l <= 8; ++l) {
+            const int e = want == WL_F48 ? (8 * l) / 3 : (128 * l) / 59;
+            if ((uint32_t)(g * e) < C) continue;
+            const long b = (long)g * l * 16;
+            if (bestb < 0 || b < bestb) { bestb = b; bg = g; bl = l; }
+            break;                                                                   // larger l only adds bytes
+          }
+        const long plain_lines = ((long)h->ld * 8 + 127) / 128, packed_lines = (bestb + 127) / 128;
+        const bool take = bestb > 0 && (want == WL_F48 || force_pack || packed_lines < plain_lines);
+        if (want == WL_F48 && bestb < 0) return fail(HPF_ERR_UNSUPPORTED);
+        if (take) {
+          const int e = want == WL_F48 ? (8 * bl) / 3 : (128 * bl) / 59;
+          h->wl = want;
+          h->phiG = bg; h->phiR = bl; h->phiV = 0;
+          h->pk.G = (uint32_t)bg; h->pk.L = (uint32_t)bl; h->pk.E = (uint32_t)e; h->pk.row_bytes = (uint32_t)(bg * bl) * 16u;
+          h->ld = (uint32_t)(bg * e);
         }
-      if (bestb < 0) return fail(HPF_ERR_UNSUPPORTED);
-      h->phiG = bg; h->phiR = bl; h->phiV = 0;
-      h->f48_E = (uint32_t)((8 * bl) / 3); h->f48_chunk = (uint32_t)bl * 16u; h->f48_row = (uint32_t)(bg * bl) * 16u;
-      h->ld = (uint32_t)bg * h->f48_E;
+      }
     }
     // the row sweep gives G' lanes to a row with R' columns each, G'*R' == ld exactly
     // (48-bit W: G'*R' >= ld, the excess columns of the last slots are masked)
@@ -1090,10 +1117,9 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     const int Gs[5] = {64, 32, 16, 8, 4};
     int best = 1 << 30;
     for (int g : Gs) {
-      if (!h->w48 && h->ld % (uint32_t)g) continue;
+      if (h->wl == WL_PLAIN && h->ld % (uint32_t)g) continue;
       const int r = (int)((h->ld + (uint32_t)g - 1) / (uint32_t)g);
       if (r < 1 || r > (g == 64 ? 16 : 8)) continue;
-      if (h->w48 && (uint32_t)(g * r) - h->ld >= (uint32_t)g && r > 1) continue;
       const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (g * 8 < 128 ? 1 : 0);   // same preferences as round 1's K sweep
       if (p < best || (p == best && g < h->swG)) { best = p; h->swG = g; h->swR = r; }
     }
@@ -1796,7 +1822,7 @@ int hpf_elbo(hpf_handle *h, double *out)
   do {
     // fp64 W: logsumexp from the hot loop's W and the row maxima of Elog (no exp per
     // element); the f32-stored W is not precise enough for that, it takes the Elog form
-    const bool from_w = !h->w32 && !h->w48 && h->nnz;
+    const bool from_w = !h->w32 && h->wl == WL_PLAIN && h->nnz;
     if (from_w) {
       if ((rc = prepare_derived(h))) break;                  // W follows a set_state(ELOG), if any
       if ((rc = dalloc(h, &Mt, h->u.rows)) || (rc = dalloc(h, &Mb, h->it.rows))) break;
@@ -2000,6 +2026,7 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->phi_G = (uint32_t)h->phiG; out->phi_R = (uint32_t)h->phiR; out->phi_V = (uint32_t)h->phiV;
   out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;
   out->ld = h->ld;
+  out->w_layout = (uint32_t)h->wl;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
 }
@@ -2048,17 +2075,19 @@ int hpf_last_timing(hpf_handle *h, hpf_timing *out) { return hpf_mean_timing(h, 
 int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item, uint64_t *rows)
 {
   if (!h) return HPF_ERR_INVALID;
-  // SURVEY.md 8(d) with s_e = s_a = 8 and K' = K + (bias ? 1 : 0).  The
+  // SURVEY.md 8(d) with s_a = 8, K' = K + (bias ? 1 : 0) and s_e = the bytes a stored element of W
+  // takes: 8 in plain rows, 59/8 in the lossless packed rows (the default at K = 100), 6 / 4 in
+  // the opt-in lossy modes -- so that "algorithmic bytes" never exceed what has to move.  The
   // item-side accumulate term nnz*K'*s_a of that formula is, in this
   // formulation, the gather of the item pass (same byte count); the item pass
   // is credited with that term only (its own index / row traffic is not
   // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
   const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
   const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
-  const uint64_t se = h->w32 ? 4 : h->w48 ? 6 : 8, sa = 8;        // bytes per stored W element / per accumulator
-  if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * se + n * Kp * (se + sa);
-  if (phi_item) *phi_item = nnz * Kp * se;
-  if (rows) *rows = (n + m) * Kp * (2 * sa + 2 * se) + 64 * (n + m);
+  const uint64_t seb = h->w32 ? 32 : h->wl == WL_F48 ? 48 : h->wl == WL_P59 ? 59 : 64, sa = 8;   // BITS per stored W element; bytes per accumulator
+  if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * seb / 8 + n * Kp * seb / 8 + n * Kp * sa;
+  if (phi_item) *phi_item = nnz * Kp * seb / 8;
+  if (rows) *rows = (n + m) * Kp * 2 * sa + (n + m) * Kp * 2 * seb / 8 + 64 * (n + m);
   return HPF_OK;
 }
 

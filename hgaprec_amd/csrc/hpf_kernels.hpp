@@ -259,68 +259,112 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 }
 
 // ---------------------------------------------------------------------
-// K1 with W stored in 48 bits per element (hpf_config.w_storage = 2, opt-in).
-// Both phi passes sit at the rate at which L2 misses are filled: the only
-// lever left is bytes per gathered row.  "f48" keeps the TOP 48 BITS of each fp64 W
-// (sign, 11 exponent bits, 36 mantissa bits; rounded to nearest even by the sweep: relative
-// error <= 2^-37 = 7.3e-12) -- K = 100 rows take five 128-byte lines instead of seven.
-// Arithmetic and accumulators stay fp64.
+// K1 over PACKED rows of W.  Both phi passes sit at the rate at which L2 misses are filled
+// (DESIGN.md section 6): the only lever left is 128-byte lines per gathered row.
 //
-// Row layout: G lane chunks of L*16 bytes.  Chunk g holds columns g*E .. g*E + E - 1,
-// E = (8 L) / 3: first the E high dwords, then the E 16-bit low parts packed two per dword.
-// Lane g of a group loads its chunk with L 16-byte loads; element e decodes with one shift
-// or mask:  bits = hi[e] << 32 | lo16[e] << 16.  Row stride of the fp64 matrices (S, E, Elog)
-// and of the exchange buffer: ld = G*E columns, lane g owning the same E columns.
+//   p59  (the default whenever it shortens the row; LOSSLESS): every W is a positive fp64 in
+//        [2^-127, 2) or zero, so its sign bit and the four high exponent bits carry nothing:
+//        52 mantissa + 7 exponent bits = 59 bits per element.  K = 100: 104 columns in 768 bytes
+//        = six lines instead of seven.  A W below 2^-127 of its row maximum (an Elog spread
+//        above 88 inside a row) cannot be stored: the sweep flushes it to zero and raises flag
+//        bit 1 (hpf_config.w_storage = 3 keeps plain fp64 rows for such states).
+//   f48  (hpf_config.w_storage = 2, opt-in, LOSSY): the top 48 bits of the fp64 value
+//        (36 mantissa bits, rounded to nearest even: 2^-37 relative).  K = 100: five lines.
+//
+// A row is L 16-byte pieces per lane for G lanes, INTERLEAVED: piece t of lane g sits at byte
+// (t*G + g)*16, so that one load instruction of a lane group reads G*16 contiguous bytes.  The
+// 4L dwords of a lane hold E elements; lane g owns columns e*G + g.  Layout of a lane's dwords
+//   p59: d[0..E)  low 32 mantissa bits of each element; then a stream of 27-bit fields
+//        (7 exponent bits above 20 mantissa bits; the all-zero element stands for 0 and reads
+//        back as 2^-127), element e at bit 27 e of the stream
+//   f48: d[0..E)  high dwords; then the 16-bit low parts, two per dword
+// Row stride of the fp64 matrices (S, E, Elog) and of the exchange buffer: ld = G*E columns.
+// Arithmetic and accumulators are fp64 in every mode.
 // ---------------------------------------------------------------------
-template <int L> struct f48 {
-  static constexpr int E = (8 * L) / 3;                   // elements per lane chunk: 2 5 8 10 13 16 18 21
-  static_assert(E + (E + 1) / 2 <= 4 * L, "chunk overflow");
+enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3 };      // layout codes (hpf_work_info.w_layout)
+
+template <int L> struct codec_f48 {
+  static constexpr int E = (8 * L) / 3;                   // 2 5 8 10 13 16 18 21
+  static_assert(E + (E + 1) / 2 <= 4 * L, "lane dwords overflow");
+  static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
+  {
+    const uint32_t lw = d[E + e / 2];
+    return __hiloint2double((int)d[e], (int)((e & 1) ? (lw & 0xffff0000u) : (lw << 16)));
+  }
 };
 
-__device__ __forceinline__ void f48_encode(double w, uint32_t *hi, uint16_t *lo)
+template <int L> struct codec_p59 {
+  static constexpr int E = (128 * L) / 59;                // 2 4 6 8 10 13 15 17
+  static_assert(E + (27 * E + 31) / 32 <= 4 * L, "lane dwords overflow");
+  static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
+  {
+    const int o = 27 * e, i = E + o / 32, sh = o % 32;    // compile-time after unrolling
+    uint32_t f;
+    if (sh + 27 <= 32) f = (d[i] >> sh) & 0x7ffffffu;     // v_bfe_u32
+    else f = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) & 0x7ffffffu;
+    // exponent field + 896.  The all-zero element (padding columns, a flushed entry) decodes to
+    // 2^-127 = 5.9e-39 instead of 0 -- one add instead of a compare and two selects per element:
+    // products of two such entries are 3e-77, below any sum they could join by sixty orders
+    return __hiloint2double((int)(f + 0x38000000u), (int)d[e]);
+  }
+};
+
+// ---- writing packed rows (row sweep, derive_w): a group of lanes builds the row in LDS -- the
+// 27-bit fields of p59 straddle dwords, so they are OR-ed in (ds_or_b32: order-free, hence
+// deterministic) -- and copies it out with 16-byte stores.  `buf` has the layout of the row.
+struct PackedRow { uint32_t G, E, L, row_bytes; };       // of the phi kernel shape
+
+__device__ __forceinline__ uint32_t packed_dword_index(const PackedRow &pk, uint32_t g, uint32_t d)
 {
+  return ((d >> 2) * pk.G + g) * 4u + (d & 3u);          // piece (d/4) of lane g, word d%4
+}
+
+__device__ __forceinline__ void packed_clear(uint32_t *buf, const PackedRow &pk, uint32_t li, uint32_t nl)
+{
+  for (uint32_t d = li; d < pk.row_bytes / 4; d += nl) buf[d] = 0u;
+}
+
+// returns true when a nonzero w had to be flushed (below 2^-127)
+__device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
+{
+  const uint32_t g = c % pk.G, e = c / pk.G;
+  const uint32_t hi = (uint32_t)__double2hiint(w), lo = (uint32_t)__double2loint(w);
+  const bool tiny = hi < 0x38100000u;                     // exponent field below 897 (or zero / negative zero)
+  const uint32_t f = tiny ? 0u : hi - 0x38000000u;
+  buf[packed_dword_index(pk, g, e)] = tiny ? 0u : lo;
+  const uint32_t o = 27u * e, i = pk.E + o / 32u, sh = o % 32u;
+  if (f) {
+    atomicOr(&buf[packed_dword_index(pk, g, i)], f << sh);
+    if (sh > 5u) atomicOr(&buf[packed_dword_index(pk, g, i + 1)], f >> (32u - sh));
+  }
+  return tiny && (w != 0.0);
+}
+
+__device__ __forceinline__ void f48_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
+{
+  const uint32_t g = c % pk.G, e = c / pk.G;
   unsigned long long b = (unsigned long long)__double_as_longlong(w);
   b += 0x7fffull + ((b >> 16) & 1ull);                    // round to nearest even at bit 16
-  *hi = (uint32_t)(b >> 32); *lo = (uint16_t)(b >> 16);
+  buf[packed_dword_index(pk, g, e)] = (uint32_t)(b >> 32);
+  atomicOr(&buf[packed_dword_index(pk, g, pk.E + e / 2)], (uint32_t)((b >> 16) & 0xffffull) << (16u * (e & 1u)));
 }
 
-// store column c of a row in the f48 layout (sweep, derive_w): E elements per 16*L-byte chunk
-__device__ __forceinline__ void f48_store(void *W, size_t row, uint32_t c, uint32_t E, uint32_t chunk_bytes,
-                                          uint32_t row_bytes, double w)
+__device__ __forceinline__ void packed_copy_out(const uint32_t *buf, void *W, size_t row, const PackedRow &pk,
+                                                uint32_t li, uint32_t nl)
 {
-  uint32_t hi; uint16_t lo;
-  f48_encode(w, &hi, &lo);
-  unsigned char *p = (unsigned char *)W + row * (size_t)row_bytes + (size_t)(c / E) * chunk_bytes;
-  const uint32_t e = c % E;
-  ((uint32_t *)p)[e] = hi;
-  ((uint16_t *)(p + 4 * E))[e] = lo;
+  uint4 *dst = reinterpret_cast<uint4 *>((unsigned char *)W + row * (size_t)pk.row_bytes);
+  const uint4 *src = reinterpret_cast<const uint4 *>(buf);
+  for (uint32_t p = li; p < pk.row_bytes / 16; p += nl) dst[p] = src[p];
 }
 
-template <int L>
-struct f48_raw { uint4 q[L]; };
-
-template <int L>
-__device__ __forceinline__ double f48_get(const f48_raw<L> &r, int e)
+template <class Codec, int G, int L>
+__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * L], const double (&own)[Codec::E],
+                                                 double (&acc)[Codec::E], float yf, bool &underflow)
 {
-  constexpr int E = f48<L>::E;
-  auto dw = [&](int k) -> uint32_t {
-    const uint4 &v = r.q[k / 4];
-    return (k % 4) == 0 ? v.x : (k % 4) == 1 ? v.y : (k % 4) == 2 ? v.z : v.w;
-  };
-  const uint32_t hi = dw(e);
-  const uint32_t lw = dw(E + e / 2);
-  const uint32_t lo = (e & 1) ? (lw & 0xffff0000u) : (lw << 16);
-  return __hiloint2double((int)hi, (int)lo);
-}
-
-template <int G, int L>
-__device__ __forceinline__ void phi_batch_f48(const f48_raw<L> &x, const double (&own)[f48<L>::E],
-                                              double (&acc)[f48<L>::E], float yf, bool &underflow)
-{
-  constexpr int E = f48<L>::E;
+  constexpr int E = Codec::E;
   double xv[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) xv[e] = f48_get<L>(x, e);
+  for (int e = 0; e < E; ++e) xv[e] = Codec::get(x, e);
   double s[2] = {0.0, 0.0};
 #pragma unroll
   for (int e = 0; e < E; ++e) s[e & 1] = (e < 2) ? own[e] * xv[e] : fma(own[e], xv[e], s[e & 1]);
@@ -333,20 +377,29 @@ __device__ __forceinline__ void phi_batch_f48(const f48_raw<L> &x, const double 
   for (int e = 0; e < E; ++e) acc[e] = fma(xv[e], scale, acc[e]);
 }
 
-template <int G, int L, int SIDE>
-__global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
+template <template <int> class CodecT, int G, int L, int SIDE>
+__global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
 {
+  using Codec = CodecT<L>;
   constexpr int NG = 64 / G;
-  constexpr int E = f48<L>::E;
+  constexpr int E = Codec::E;
   constexpr uint32_t LD = G * E;                 // columns: stride of S / partial
   constexpr uint32_t ROWB = G * L * 16;          // bytes of a W row
   const int lane = threadIdx.x & 63;
   const int g = lane % G, q = lane / G;
   const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * (L * 16);
-  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * (L * 16);
+  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
+  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
   bool underflow = false;
+
+  auto load_row = [&](uint32_t (&d)[4 * L], const unsigned char *base) {
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
+      d[4 * t] = v.x; d[4 * t + 1] = v.y; d[4 * t + 2] = v.z; d[4 * t + 3] = v.w;
+    }
+  };
 
   for (uint32_t s = wave; s < a.nseg; s += nwaves) {
     const Seg sg = a.segs[s];
@@ -354,12 +407,10 @@ __global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
     const int64_t start = sg.start;
     double own[E], acc[E];
     {
-      f48_raw<L> r;
-      const uint4 *wo = reinterpret_cast<const uint4 *>(W_own + (size_t)sg.row * ROWB);
+      uint32_t r[4 * L];
+      load_row(r, W_own + (size_t)sg.row * ROWB);
 #pragma unroll
-      for (int t = 0; t < L; ++t) r.q[t] = wo[t];
-#pragma unroll
-      for (int e = 0; e < E; ++e) { own[e] = f48_get<L>(r, e); acc[e] = 0.0; }
+      for (int e = 0; e < E; ++e) { own[e] = Codec::get(r, e); acc[e] = 0.0; }
     }
     if (len > 0) {
       auto load_i = [&](uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
@@ -372,15 +423,13 @@ __global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
       uint32_t cur_i = load_i((uint32_t)lane), nxt_i = load_i(64u + lane);
       float cur_y = load_y((uint32_t)lane), nxt_y = load_y(64u + lane);
       const uint32_t nb = (len + NG - 1) / NG;
-      f48_raw<L> xa, xb;
+      uint32_t xa[4 * L], xb[4 * L];
       float ya, yb = 0.0f;
-      auto gather = [&](f48_raw<L> &x, float &y, uint32_t b) {
+      auto gather = [&](uint32_t (&x)[4 * L], float &y, uint32_t b) {
         const int src = (int)((b % G) * NG) + q;
         const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
         y = __shfl(cur_y, src, 64);
-        const uint4 *p = reinterpret_cast<const uint4 *>(W_oth + (size_t)in * ROWB);
-#pragma unroll
-        for (int t = 0; t < L; ++t) x.q[t] = p[t];
+        load_row(x, W_oth + (size_t)in * ROWB);
       };
       auto next_chunk = [&](uint32_t b) {
         cur_i = nxt_i; cur_y = nxt_y;
@@ -392,15 +441,15 @@ __global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
       if (nb > 1) gather(xb, yb, 1);
       uint32_t bb = 0;
       for (; bb + 3 < nb; bb += 2) {
-        phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+        phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
         __builtin_amdgcn_sched_barrier(0);
         if (((bb + 2) % G) == 0) next_chunk(bb + 2);
         gather(xa, ya, bb + 2);
-        phi_batch_f48<G, L>(xb, own, acc, yb, underflow);
+        phi_batch_packed<Codec, G, L>(xb, own, acc, yb, underflow);
         __builtin_amdgcn_sched_barrier(0);
         gather(xb, yb, bb + 3);
       }
-      phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+      phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
       if (bb + 1 < nb) {
         const bool third = bb + 2 < nb;
         __builtin_amdgcn_sched_barrier(0);
@@ -408,11 +457,11 @@ __global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
           if (((bb + 2) % G) == 0) next_chunk(bb + 2);
           gather(xa, ya, bb + 2);
         }
-        phi_batch_f48<G, L>(xb, own, acc, yb, underflow);
-        if (third) phi_batch_f48<G, L>(xa, own, acc, ya, underflow);
+        phi_batch_packed<Codec, G, L>(xb, own, acc, yb, underflow);
+        if (third) phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
       }
     }
-    double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + (size_t)g * E;
+    double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + g;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       double r = acc[e];
@@ -420,7 +469,7 @@ __global__ __launch_bounds__(256) void phi_pass_f48_kernel(PhiArgs a)
       if (G <= 16) r += __shfl_xor(r, 16, 64);
       if (G <= 8)  r += __shfl_xor(r, 8, 64);
       if (G <= 4)  r += __shfl_xor(r, 4, 64);
-      if (q == 0) dst[e] = own[e] * r;
+      if (q == 0) dst[(size_t)e * G] = own[e] * r;
     }
   }
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
@@ -571,7 +620,8 @@ struct SweepArgs {
   const double *colsum_oth; // [ld]   sum over the other side's rows of E
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
-  uint32_t      f48_E, f48_chunk, f48_row;   // w_storage = 2: elements and bytes per lane chunk, bytes per W row
+  PackedRow     pk;         // packed W rows (WL != WL_PLAIN): the phi kernel's G, E, L and the row bytes
+  uint32_t     *flags;      // bit 1: a nonzero W below 2^-127 was flushed by the p59 layout
   int32_t       bias_col;   // column holding this side's bias (-1: none)
   int32_t       junk_col;   // column holding the other side's bias (-1: none)
   double        bias_rate_add;  // n_other_total for the bias column
@@ -579,14 +629,16 @@ struct SweepArgs {
   uint32_t      hier;
 };
 
-// F48 = false: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no
-// column test.  F48 = true (w_storage = 2): the stride a.ld = G_phi * E may be smaller than G*R; the
-// slots from tb on then also hold columns past the end of the row, whose loads and stores are
-// masked, and W goes out in the 48-bit layout of phi_pass_f48_kernel.
-template <int G, int R, bool F48>
+// WL = WL_PLAIN: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no
+// column test.  Packed layouts (WL_P59, WL_F48): the stride a.ld = G_phi * E may be smaller than
+// G*R; the slots from tb on then also hold columns past the end of the row, whose loads and
+// stores are masked, and the group builds the packed row in LDS before it goes out.
+template <int G, int R, int WL>
 __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 {
+  constexpr bool F48 = WL != WL_PLAIN;           // (historic name) any packed layout
   const uint32_t LD = F48 ? a.ld : (uint32_t)(G * R);
+  __shared__ uint32_t pkbuf[F48 ? 512 * R : 1];  // 256/G groups x (<= 2*G*R dwords of packed row)
   __shared__ double red[4][G * R];       // per-wave column partials
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane % G, q = lane / G;
@@ -660,9 +712,17 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     rsum = group_sum<G>(rsum);
     const double inv = (wmax > 0.0) ? fast_rcp(wmax) : 0.0;
     if (F48) {
+      uint32_t *buf = pkbuf + (threadIdx.x / G) * (2 * G * R);
+      packed_clear(buf, a.pk, (uint32_t)g, (uint32_t)G);
+      bool flushed = false;
 #pragma unroll
       for (int t = 0; t < R; ++t)
-        if ((uint32_t)(g + G * t) < LD) f48_store(a.W, row, g + G * t, a.f48_E, a.f48_chunk, a.f48_row, w[t] * inv);
+        if ((uint32_t)(g + G * t) < LD) {
+          if (WL == WL_P59) flushed |= p59_put(buf, a.pk, g + G * t, w[t] * inv);
+          else f48_put(buf, a.pk, g + G * t, w[t] * inv);
+        }
+      packed_copy_out(buf, a.W, row, a.pk, (uint32_t)g, (uint32_t)G);
+      if (flushed) atomicOr(a.flags, 2u);
     } else if (a.w32) {
 #pragma unroll
       for (int t = 0; t < R; ++t) ((float *)a.W)[base + g + G * t] = (float)(w[t] * inv);
@@ -792,14 +852,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
 }
 
 // W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
-// wmode: 0 double, 1 float, 2 the 48-bit layout (f48_E elements per f48_chunk-byte lane chunk)
-__global__ void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32_t rows,
+// wmode: 0 double, 1 float, WL_F48 / WL_P59 the packed layouts (built per row in LDS)
+__global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32_t rows,
                                 uint32_t ld, uint32_t K, int32_t bias_col,
-                                int32_t junk_col, uint32_t f48_E, uint32_t f48_chunk, uint32_t f48_row)
+                                int32_t junk_col, PackedRow pk, uint32_t *flags)
 {
+  __shared__ uint32_t pkbuf[4][2304];            // a packed row per wave (<= 64 lanes x 8 pieces x 16 B + slack)
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t *buf = pkbuf[threadIdx.x >> 6];
+  const bool packed = wmode == WL_P59 || wmode == WL_F48;
+  bool flushed = false;
   for (uint32_t row = wave; row < rows; row += nwaves) {
     double m = -1.0e308;
     for (uint32_t c = lane; c < ld; c += 64) {
@@ -807,14 +871,18 @@ __global__ void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32
       if (live) m = fmax(m, L[(size_t)row * ld + c]);
     }
     m = group_max<64>(m);
+    if (packed) packed_clear(buf, pk, (uint32_t)lane, 64u);
     for (uint32_t c = lane; c < ld; c += 64) {
       const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
       const double wv = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
-      if (wmode == 2) f48_store(W, row, c, f48_E, f48_chunk, f48_row, wv);
+      if (wmode == WL_P59) flushed |= p59_put(buf, pk, c, wv);
+      else if (wmode == WL_F48) f48_put(buf, pk, c, wv);
       else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
       else ((double *)W)[(size_t)row * ld + c] = wv;
     }
+    if (packed) packed_copy_out(buf, W, row, pk, (uint32_t)lane, 64u);
   }
+  if (flushed) atomicOr(flags, 2u);
 }
 
 // ---------------------------------------------------------------------

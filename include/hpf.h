@@ -85,7 +85,16 @@ typedef struct {
   uint32_t w_storage;      /* how W = exp(Elog - rowmax), the matrix the phi      */
                            /* passes gather, is stored (arithmetic and             */
                            /* accumulators are fp64 in every mode):                */
-                           /* 0: fp64 (default; the only mode chosen implicitly).  */
+                           /* 0: fp64, exact (default; the only mode chosen        */
+                           /*    implicitly).  The library may PACK the rows       */
+                           /*    losslessly (59 bits per element: every W is a     */
+                           /*    positive double in [2^-127, 2) or zero, so the    */
+                           /*    sign and four exponent bits carry nothing) when   */
+                           /*    that saves a 128-byte line per row -- K = 100:    */
+                           /*    six lines instead of seven.  A W below 2^-127 of  */
+                           /*    its row maximum (Elog spread > 88 inside a row)   */
+                           /*    cannot be packed: HPF_ERR_STATE, use 3.           */
+                           /* 3: fp64 in plain rows, never packed.                 */
                            /* 1: EXPERIMENTAL fp32 -- drifts out of the 1e-4       */
                            /*    parity contract after ~30 iterations. */
                            /* 2: OPT-IN 48 bits: the top 48 bits of the fp64 value */
@@ -291,7 +300,9 @@ typedef struct {
   uint32_t sweep_G, sweep_R;         /* row sweep: lanes per row, columns per lane */
   uint32_t ld;                       /* row stride of the device matrices, doubles */
   uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
-  uint32_t reserved[3];
+  uint32_t w_layout;                 /* rows of W: 0 plain (phi_V elements per load), 3 packed 59-bit (lossless),  */
+                                     /* 2 packed 48-bit (w_storage = 2); packed: phi_R = 16-byte pieces per lane   */
+  uint32_t reserved[2];
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 

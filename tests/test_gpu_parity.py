@@ -524,7 +524,7 @@ def test_48_bit_stored_w_opt_in_mode(orc, K, hier, bias, binary):
         D.iterate(6)
         outs.append([D.get_state(w) for w in compare_states(hier, bias)])
     M.iterate(6)
-    assert wi["ld"] >= K + (2 if bias else 0) and wi["phi_V"] == 0            # the 48-bit kernel shape
+    assert wi["ld"] >= K + (2 if bias else 0) and wi["phi_V"] == 0 and wi["w_layout"] == 2     # the 48-bit kernel shape
     assert all(np.array_equal(a, b) for a, b in zip(*outs))                   # deterministic
     worst = 0.0
     for w, a in zip(compare_states(hier, bias), outs[0]):
@@ -536,6 +536,62 @@ def test_48_bit_stored_w_opt_in_mode(orc, K, hier, bias, binary):
     assert abs(D.elbo() - M.elbo()) <= 1e-8 * abs(M.elbo())
     if K >= 20:
         assert worst > 1e-13                                                  # it really is a different storage precision
+
+
+@pytest.mark.parametrize("K,hier,bias,binary", [(5, True, False, False), (5, True, True, False), (7, False, True, False),
+                                                (21, True, True, False), (50, True, False, True), (100, True, False, False),
+                                                (102, False, True, False), (200, True, True, False)])
+@pytest.mark.parametrize("pack", ["packed", "plain"])
+def test_lossless_packed_rows_and_plain_rows_both_match_the_oracle(orc, monkeypatch, K, hier, bias, binary, pack):
+    """W rows are stored either as plain fp64 or LOSSLESSLY packed at 59 bits per element (sign and
+    four exponent bits of a positive double <= 1 carry nothing).  The library packs by default where
+    that saves a 128-byte line per row (K = 100: yes); here every shape is run both ways -- packing
+    forced through HPF_W_PACK=1, plain rows through w_storage = 3 -- against the oracle at the
+    same tolerance as the default path."""
+    if pack == "packed":
+        monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+        monkeypatch.setenv("HPF_W_PACK", "1")
+    M, D = _run_pair(orc, 300, 200, K, 6000, hier, bias, binary, 6, seed=11 + K, w_storage=0 if pack == "packed" else 3)
+    wi = D.work_info()
+    assert wi["w_layout"] == (3 if pack == "packed" else 0), wi
+    hu, hi, hy = heldout_pairs(300, 200, 500, seed=5)
+    for it in range(6):
+        M.iterate(1)
+        D.iterate(1)
+        for w in compare_states(hier, bias):
+            e = rel_err(D.get_state(w), M.state(w))
+            assert e < RTOL, f"{pack} iter {it} {w}: rel err {e:.3e}"
+    assert abs(D.heldout_ll(hu, hi, hy)[0] - M.heldout_sum(hu, hi, hy)) / hu.size < 1e-9
+    assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
+
+
+def test_default_packs_k100_rows_and_refuses_what_it_cannot_hold(orc):
+    """K = 100: 104 columns x 59 bits = 768 bytes, six lines instead of seven, chosen by default.
+    A W entry below 2^-127 of its row maximum (an Elog spread above 88 inside a row -- no HPF
+    state has one) cannot be packed: the iteration reports it instead of dropping it silently;
+    plain rows (w_storage = 3) take such a state."""
+    from hgaprec_amd.capi import Hpf, HpfError
+    n, m, K = 200, 150, 100
+    M, D = _run_pair(orc, n, m, K, 4000, True, False, False, 2, seed=3)
+    wi = D.work_info()
+    assert wi["w_layout"] == 3 and wi["ld"] == 104 and wi["phi_G"] * wi["phi_R"] * 16 == 768
+    D.iterate(2); M.iterate(2)
+    assert rel_err(D.get_state("BETA_E"), M.state("BETA_E")) < RTOL
+    el = D.get_state("THETA_ELOG")
+    el[:, 0] -= 120.0                                   # exp(-120) = 7.7e-53 < 2^-127
+    for ws, ok in ((0, False), (3, True)):
+        E = Hpf(n, m, K, hier=True, w_storage=ws)
+        rowptr, col, val = make_problem(n, m, 4000, 3)
+        E.upload_csr(rowptr, col, val)
+        copy_state(M, E, True, False)
+        E.set_state("THETA_ELOG", el)
+        if ok:
+            E.iterate(1); E.synchronize()
+            assert np.isfinite(E.get_state("THETA_E")).all()
+        else:
+            with pytest.raises(HpfError, match="2\\^-127"):
+                E.iterate(1); E.get_state("THETA_E")
+        E.close()
 
 
 def test_48_bit_stored_w_stays_inside_the_contract_over_a_long_run(orc):
