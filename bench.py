@@ -467,7 +467,8 @@ def main():
         # dominant kernel of the iteration and its HBM roofline position
         kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
         kms = tm[kern + "_ms"]
-        kname, kbytes = f"phi_pass_kernel ({kern} pass)", ab[kern]
+        kname = {0: "phi_pass_kernel", 2: "phi_pass_packed_kernel<codec_f48>", 3: "phi_pass_packed_kernel<codec_p59>"}.get(wi["w_layout"], "phi pass")
+        kname, kbytes = f"{kname} ({kern} pass)", ab[kern]
         graph = kms == 0
         if graph:
             # launch-bound workload: hpf_iterate replayed the iteration as one
