@@ -81,6 +81,14 @@ struct hpf_handle {
   // item rate is built from the sum_u E[theta] of BEFORE this iteration's user sweep
   bool jacobi = false;
   double *u_colsum_prev = nullptr;      // [ld]
+  // One GPU, problems too large for the graph replay: the user sweep runs on a second stream
+  // UNDERNEATH the item-major phi pass (iterate_overlapped).  The item pass still reads the W of
+  // the users, so the sweep writes the new one into a spare buffer and the two are swapped.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void *u_W_spare = nullptr;
+  bool overlap_sweep = false;           // HPF_OVERLAP=1 (experimental).  Measured at C2: iteration 9.67 -> 9.53 ms, but the
+                                        // item pass beside the sweep takes 5.66 instead of 5.29 ms: off by default
   double *logfact = nullptr;
   int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ranking mask, CSC build)
   int64_t *colptr_dev = nullptr;   // item-major (CSC) column pointers, built on device
@@ -119,6 +127,7 @@ struct hpf_handle {
   bool capturing = false;               // inside stream capture: no events, no counters
   int phase = 0;                        // 0 idle | 1 items pass done | 2 users pass done | 3 user sweep done
   bool ring_graphed[RING] = {};         // slot was a graph replay: only events 0 and 6 exist
+  bool ring_overlapped[RING] = {};      // slot ran iterate_overlapped: user pass first, user sweep beside the item pass
   std::string err;
 };
 
@@ -819,12 +828,16 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   return check_launch(h, "phi pass");
 }
 
-int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_out)
+// st / W_out: the stream the sweep runs on and the buffer its W goes to (defaults: the handle's
+// stream, the side's W; iterate_overlapped passes a second stream and the spare buffer)
+int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_out, hipStream_t st = nullptr,
+              void *W_out = nullptr)
 {
+  if (!st) st = h->stream;
   // remember what the rate was built from (export of *_rate.tsv)
-  HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, st));
   SweepArgs a;
-  a.S = s.S; a.W = s.W; a.w32 = h->w32;
+  a.S = s.S; a.W = W_out ? W_out : s.W; a.w32 = h->w32;
   a.pk = h->pk; a.flags = h->flags;
   s.l_stale = true; s.es_stale = true;
   a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
@@ -833,14 +846,14 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->wl, h->swG, h->swR, a, s.sweep_blocks, h->stream)) {
+  if (!launch_sweep(h->wl, h->swG, h->swR, a, s.sweep_blocks, st)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   if (h->cfg.hier && s.rows)                // xi / eta: E and Elog from the rate the sweep just wrote
-    hipLaunchKernelGGL(prior_update_kernel, dim3(std::min<uint32_t>((s.rows + 255) / 256, 4096)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(prior_update_kernel, dim3(std::min<uint32_t>((s.rows + 255) / 256, 4096)), dim3(256), 0, st,
                        s.prior_E, s.prior_used, s.prior_rate, s.prior_elog, s.prior_elog_used, s.rows,
                        h->cfg.s_prior + (double)h->K * h->cfg.s_prior, a.psi_prior_shape);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, st,
                      s.colsum_part, s.sweep_blocks, h->ld, colsum_out);
   return check_launch(h, "row sweep");
 }
@@ -860,6 +873,7 @@ int phi_items(hpf_handle *h)
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
   h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
+  h->ring_overlapped[h->ev_count % hpf_handle::RING] = false;
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;   // step A, beta shape sums
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -930,6 +944,58 @@ int iterate_global(hpf_handle *h)
   return HPF_OK;
 }
 
+// One whole iteration on one GPU with the user sweep hidden under the item-major pass:
+//   main stream:  user pass | ................ item pass ............... | join, swap W | item sweep
+//   side stream:            | user sweep -> spare W, xi, sum_u E[theta]  |
+// Same kernels on the same inputs as iterate_local + iterate_global (the two phi passes are
+// independent of each other and the user sweep reads only what the user pass wrote), so the
+// results are bit-identical; only the order of the two passes and the stream of the sweep differ.
+int iterate_overlapped(hpf_handle *h)
+{
+  int rc;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if (h->phase != 0) { h->err = "call order: an iteration is already in flight"; return HPF_ERR_STATE; }
+  if ((rc = prepare_derived(h))) return rc;
+  if (!h->side_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    double *w = nullptr;
+    if ((rc = dalloc(h, &w, (size_t)h->u.rows * h->ld))) {
+      if (rc != HPF_ERR_OOM) return rc;
+      (void)hipGetLastError();                             // no room for the spare matrix: plain sequence from now on
+      h->overlap_sweep = false;
+      if ((rc = iterate_local(h))) return rc;
+      return iterate_global(h);
+    }
+    h->u_W_spare = w;
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // dalloc cleared it on the main stream
+  }
+  const uint32_t slot = h->ev_count % hpf_handle::RING;
+  h->ev = h->evr[slot];
+  h->ring_graphed[slot] = false; h->ring_overlapped[slot] = true;
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  if ((rc = run_phi(h, h->u, h->it, h->ev[3]))) return rc;             // theta shape sums
+  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+  if (h->jacobi)
+    HIPCHK(h, hipMemcpyAsync(h->u_colsum_prev, h->u.colsum, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->side_stream));
+  if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum, h->side_stream, h->u_W_spare))) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[5], h->side_stream));
+  HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+  if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;             // beta shape sums, from the OLD W of the users
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  std::swap(h->u.W, h->u_W_spare);
+  HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
+  if ((rc = run_sweep(h, h->it, h->jacobi ? h->u_colsum_prev : h->u.colsum, h->it.colsum))) return rc;
+  HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
+  h->ev_count++;
+  h->iterations++;
+  return HPF_OK;
+}
+
 void drop_graph(hpf_handle *h)
 {
   if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -970,7 +1036,7 @@ int iterate_graph(hpf_handle *h, int n_iters)
   for (int t = 0; t < n_iters; ++t) {
     const uint32_t slot = h->ev_count % hpf_handle::RING;
     h->ev = h->evr[slot];
-    h->ring_graphed[slot] = true;
+    h->ring_graphed[slot] = true; h->ring_overlapped[slot] = false;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
@@ -1132,6 +1198,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   }
   if (const char *e = knob("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
   if (const char *e = knob("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
+  if (const char *e = knob("HPF_OVERLAP")) h->overlap_sweep = atoi(e) != 0;
   if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
@@ -1193,6 +1260,12 @@ void hpf_destroy(hpf_handle *h)
     (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_reduced);
     (void)hipStreamDestroy(h->comm_stream);
   }
+  if (h->side_stream) {
+    (void)hipStreamSynchronize(h->side_stream);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->side_stream);
+  }
+  dfree(h->u_W_spare);
   double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
   h->u.colsum = nullptr;
   double *icol = h->it.colsum; h->it.colsum = nullptr;
@@ -1749,6 +1822,7 @@ int hpf_iterate(hpf_handle *h, int n_iters)
   if (n_iters > 0 && want_graph(h)) return iterate_graph(h, n_iters);
   for (int t = 0; t < n_iters; ++t) {
     int rc;
+    if (h->overlap_sweep) { if ((rc = iterate_overlapped(h))) return rc; continue; }
     if ((rc = iterate_local(h))) return rc;
     if ((rc = iterate_global(h))) return rc;
   }
@@ -2051,7 +2125,15 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
     hipEvent_t *ev = h->evr[slot];
     float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // a graph-replayed iteration is one launch: only its total is known
-    if (!h->ring_graphed[slot]) {
+    if (h->ring_overlapped[slot] && !h->ring_graphed[slot]) {
+      // user pass first; the user sweep ran on the side stream while the item pass ran on the main one
+      HIPCHK(h, hipEventElapsedTime(&ms[2], ev[0], ev[3]));      // user pass
+      HIPCHK(h, hipEventElapsedTime(&ms[3], ev[3], ev[4]));      // its combine
+      HIPCHK(h, hipEventElapsedTime(&ms[0], ev[4], ev[1]));      // item pass (the user sweep beside it)
+      HIPCHK(h, hipEventElapsedTime(&ms[1], ev[1], ev[2]));      // its combine
+      HIPCHK(h, hipEventElapsedTime(&ms[4], ev[4], ev[5]));      // user sweep, start of the fork -> its last kernel
+      HIPCHK(h, hipEventElapsedTime(&ms[5], ev[7], ev[6]));      // item sweep
+    } else if (!h->ring_graphed[slot]) {
       for (int j = 0; j < 5; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
       HIPCHK(h, hipEventElapsedTime(&ms[7], ev[5], ev[7]));      // exchange the stream waited for
       HIPCHK(h, hipEventElapsedTime(&ms[5], ev[7], ev[6]));      // the item sweep itself
