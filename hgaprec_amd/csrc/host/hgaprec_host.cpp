@@ -378,7 +378,7 @@ template <typename T> bool get_vec(FILE *f, std::vector<T> *v, size_t cnt)
 }
 }  // namespace
 
-int Ratings::save_cache(const std::string &dir) const
+int Ratings::save_cache(const std::string &dir, const std::string &image) const
 {
   CacheHeader h;
   memset(&h, 0, sizeof h);
@@ -386,7 +386,7 @@ int Ratings::save_cache(const std::string &dir) const
   h.cap_n = cap_n; h.cap_m = cap_m; h.binary = binary; h.rating_threshold = rating_threshold;
   if (!fingerprint(dir, &h)) return -1;
   h.n = n; h.m = m; h.nnz = col.size(); h.n_validation = validation.u.size(); h.n_test = test.u.size();
-  const std::string path = dir + "/hgaprec.cache.bin", tmp = path + ".tmp." + std::to_string((long)getpid());
+  const std::string path = image.empty() ? dir + "/hgaprec.cache.bin" : image, tmp = path + ".tmp." + std::to_string((long)getpid());
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return -1;
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
@@ -400,9 +400,9 @@ int Ratings::save_cache(const std::string &dir) const
   return 0;
 }
 
-int Ratings::load_cache(const std::string &dir)
+int Ratings::load_cache(const std::string &dir, const std::string &image)
 {
-  FILE *f = fopen((dir + "/hgaprec.cache.bin").c_str(), "rb");
+  FILE *f = fopen((image.empty() ? dir + "/hgaprec.cache.bin" : image).c_str(), "rb");
   if (!f) return 1;
   CacheHeader h, want;
   memset(&want, 0, sizeof want);

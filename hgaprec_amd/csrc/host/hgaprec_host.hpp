@@ -98,8 +98,11 @@ struct Ratings {
   // fingerprinted by size and mtime).  load: 0 = loaded, 1 = absent / stale /
   // other parameters / truncated (parse the TSVs instead).  save: 0 or -1.
   bool heldout_loaded = false;
-  int save_cache(const std::string &dir) const;
-  int load_cache(const std::string &dir);
+  // `image`: where the image lives (default <dir>/hgaprec.cache.bin); the fingerprint is always
+  // that of the TSV files in `dir`.  `-ngpus N` uses an image in the output directory to hand the
+  // parsed data set from rank 0 to the other ranks.
+  int save_cache(const std::string &dir, const std::string &image = "") const;
+  int load_cache(const std::string &dir, const std::string &image = "");
 
  // open-addressing id -> seq maps (std::map in the reference; only lookups
   // and insertion order matter)

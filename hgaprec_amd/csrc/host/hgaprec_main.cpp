@@ -672,9 +672,44 @@ int main(int argc, char **argv)
   ratings.binary = env.binary_data; ratings.rating_threshold = env.rating_threshold;
   if (rank == 0) { fprintf(stdout, "+ reading ratings dataset from %s\n", env.datfname.c_str()); fflush(stdout); }
   int rc = 0;
+  bool have_data = false;
   if (env.data_cache && ratings.load_cache(env.datfname) == 0) {
     if (rank == 0) env.lerr("-cache: loaded %s/hgaprec.cache.bin", env.datfname.c_str());
-  } else rc = ratings.read_train(env.datfname + "/train.tsv");
+    have_data = true;
+  } else if (world > 1) {
+    // Several ranks, no cache image: rank 0 alone parses the TSVs (train, validation, test) and
+    // hands the parsed data set to the others through an image in the output directory -- N
+    // parsers of the same text were the set-up cost of `-ngpus N`.
+    const std::string handoff = env.file_str("/ranks.cache.bin");
+    double ok = 1.0;
+    if (rank == 0) {
+      rc = ratings.read_train(env.datfname + "/train.tsv");
+      if (rc) exit(-1);
+      int r2 = ratings.read_heldout(env.datfname + "/validation.tsv", &ratings.validation);
+      assert(r2 != -1);
+      if (r2) exit(-1);
+      r2 = ratings.read_heldout(env.datfname + "/test.tsv", &ratings.test);
+      assert(r2 != -1);
+      if (r2) exit(-1);
+      ratings.heldout_loaded = true;
+      if (env.data_cache) {
+        if (ratings.save_cache(env.datfname)) env.lerr("-cache: cannot write %s/hgaprec.cache.bin", env.datfname.c_str());
+        else env.lerr("-cache: wrote %s/hgaprec.cache.bin", env.datfname.c_str());
+      }
+      ok = ratings.save_cache(env.datfname, handoff) == 0 ? 1.0 : 0.0;
+      have_data = true;
+    }
+    if (comm.allreduce_max(&ok, 1)) return 1;            // also the barrier the others wait at
+    double got = 1.0;
+    if (rank != 0) {
+      got = (ok > 0 && ratings.load_cache(env.datfname, handoff) == 0) ? 1.0 : 0.0;
+      if (got > 0) { have_data = true; fprintf(stderr, "[rank %d] ratings handed over by rank 0 (%s)\n", rank, handoff.c_str()); }
+    }
+    double neg = -got;                                    // min over ranks: everybody is done with the image
+    if (comm.allreduce_max(&neg, 1)) return 1;
+    if (rank == 0) remove(handoff.c_str());
+  }
+  if (!have_data) rc = ratings.read_train(env.datfname + "/train.tsv");
   if (rc) exit(-1);
   if (rank == 0) {
     env.plog("training ratings", (uint32_t)ratings.nratings);

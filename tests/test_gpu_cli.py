@@ -170,6 +170,8 @@ def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
     assert len(outs) == 1
     out = outs[0]
     assert not [p for p in out.iterdir() if ".part" in p.name]          # all part files merged
+    # rank 0 alone parsed the TSVs; rank 1 took the parsed data set from its image, which is gone again
+    assert "[rank 1] ratings handed over by rank 0" in r.stderr and not (out / "ranks.cache.bin").exists()
     ref = tmp_path / "oracle_out"
     ref.mkdir()
     orc.run(data, ref, n, m, K, hier=hier, bias=bias, rfreq=rfreq,
