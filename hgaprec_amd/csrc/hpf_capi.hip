@@ -353,7 +353,7 @@ int check_flags(hpf_handle *h)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (f & 2u) {
     h->err = "an entry of W fell below 2^-127 of its row maximum (Elog spread > 88 inside a row): the packed row layout "
-             "cannot hold it; create the handle with w_storage = 3 (plain fp64 rows)";
+             "cannot hold it; create the handle with w_storage = 3 (plain fp64 rows; `hgaprec -plain-rows`)";
     return HPF_ERR_STATE;
   }
   if (f & 1u) {

@@ -56,7 +56,8 @@ def series(p):
     (["-bias"], 5, None),          # vb_bias()
     (["-bias", "-novb"], 5, None), # vb_bias(), -novb: both rates from the previous iteration (hgaprec.cc:1276-1297)
     (["-hier", "-novb"], 5, 8),    # vb_hier() never reads the flag; only the directory name changes
-    (["-hier"], 100, 6),
+    (["-hier"], 100, 6),               # K = 100: rows of W packed at 59 bits (the library's default there)
+    (["-hier", "-plain-rows"], 100, 4),  # ... and kept plain (extension flag, hpf_config.w_storage = 3)
     (["-hier", "-bias", "-logl"], 6, 8),
     (["-logl"], 4, None),
     (["-hier", "-rfreq", "50"], 5, 100),      # iteration 100: ranking.tsv + itemrank.tsv + meanrank.txt
