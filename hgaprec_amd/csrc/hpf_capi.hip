@@ -71,7 +71,7 @@ struct hpf_handle {
   bool w32 = false;                     // W stored as float (hpf_config.w_storage = 1)
   int wl = WL_PLAIN;                    // layout of W rows: plain, WL_P59 (lossless packing, default where it shortens
                                         // the row) or WL_F48 (w_storage = 2); packed: phiR = 16-byte pieces per lane
-  PackedRow pk = {0, 0, 0, 0};
+  PackedRow pk = {0, 0, 0, 0, 0};
   uint32_t *flags = nullptr;            // device word: bit 0 = a softmax denominator underflowed
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -1166,13 +1166,22 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
             break;                                                                   // larger l only adds bytes
           }
         const long plain_lines = ((long)h->ld * 8 + 127) / 128, packed_lines = (bestb + 127) / 128;
-        const bool take = bestb > 0 && (want == WL_F48 || force_pack || packed_lines < plain_lines);
+        bool take = bestb > 0 && (want == WL_F48 || force_pack || packed_lines < plain_lines);
         if (want == WL_F48 && bestb < 0) return fail(HPF_ERR_UNSUPPORTED);
+        // the sweep must have a shape for the packed stride too (G' * R' >= ld, R' <= 8, 16 at G' = 64)
+        if (take) {
+          const uint32_t pld = (uint32_t)(bg * (want == WL_F48 ? (8 * bl) / 3 : (128 * bl) / 59));
+          bool fits = false;
+          for (int g : {64, 32, 16, 8, 4}) { const uint32_t r = (pld + (uint32_t)g - 1) / (uint32_t)g; fits |= r >= 1 && r <= (g == 64 ? 16u : 8u); }
+          if (!fits && want == WL_F48) return fail(HPF_ERR_UNSUPPORTED);
+          if (!fits) take = false;                         // e.g. 961..1024 columns: 1088 packed columns have none; rows stay plain
+        }
         if (take) {
           const int e = want == WL_F48 ? (8 * bl) / 3 : (128 * bl) / 59;
           h->wl = want;
           h->phiG = bg; h->phiR = bl; h->phiV = 0;
           h->pk.G = (uint32_t)bg; h->pk.L = (uint32_t)bl; h->pk.E = (uint32_t)e; h->pk.row_bytes = (uint32_t)(bg * bl) * 16u;
+          h->pk.lgG = 0; while ((1u << h->pk.lgG) < (uint32_t)bg) ++h->pk.lgG;
           h->ld = (uint32_t)(bg * e);
         }
       }

@@ -312,11 +312,11 @@ template <int L> struct codec_p59 {
 // ---- writing packed rows (row sweep, derive_w): a group of lanes builds the row in LDS -- the
 // 27-bit fields of p59 straddle dwords, so they are OR-ed in (ds_or_b32: order-free, hence
 // deterministic) -- and copies it out with 16-byte stores.  `buf` has the layout of the row.
-struct PackedRow { uint32_t G, E, L, row_bytes; };       // of the phi kernel shape
+struct PackedRow { uint32_t G, E, L, row_bytes, lgG; };  // of the phi kernel shape (G = 1 << lgG: no integer division)
 
 __device__ __forceinline__ uint32_t packed_dword_index(const PackedRow &pk, uint32_t g, uint32_t d)
 {
-  return ((d >> 2) * pk.G + g) * 4u + (d & 3u);          // piece (d/4) of lane g, word d%4
+  return ((((d >> 2) << pk.lgG) + g) << 2) + (d & 3u);   // piece (d/4) of lane g, word d%4
 }
 
 __device__ __forceinline__ void packed_clear(uint32_t *buf, const PackedRow &pk, uint32_t li, uint32_t nl)
@@ -327,7 +327,7 @@ __device__ __forceinline__ void packed_clear(uint32_t *buf, const PackedRow &pk,
 // returns true when a nonzero w had to be flushed (below 2^-127)
 __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
 {
-  const uint32_t g = c % pk.G, e = c / pk.G;
+  const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
   const uint32_t hi = (uint32_t)__double2hiint(w), lo = (uint32_t)__double2loint(w);
   const bool tiny = hi < 0x38100000u;                     // exponent field below 897 (or zero / negative zero)
   const uint32_t f = tiny ? 0u : hi - 0x38000000u;
@@ -342,7 +342,7 @@ __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint
 
 __device__ __forceinline__ void f48_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
 {
-  const uint32_t g = c % pk.G, e = c / pk.G;
+  const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
   unsigned long long b = (unsigned long long)__double_as_longlong(w);
   b += 0x7fffull + ((b >> 16) & 1ull);                    // round to nearest even at bit 16
   buf[packed_dword_index(pk, g, e)] = (uint32_t)(b >> 32);

@@ -599,6 +599,19 @@ def test_lossless_packed_rows_and_plain_rows_both_match_the_oracle(orc, monkeypa
     assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
 
 
+@pytest.mark.parametrize("K,layout", [(900, 3), (1000, 0), (1022, 0)])
+def test_widest_rows_pack_when_the_sweep_has_a_shape_for_them(orc, K, layout):
+    """K near HPF_MAX_COLUMNS: 900 columns pack (64 lanes x 15 = 960 columns, 56 lines instead of 64);
+    from 961 live columns on the packed stride would be 1088 columns, for which the sweep has no
+    shape: rows stay plain (1024 columns) instead of the handle being refused."""
+    M, D = _run_pair(orc, 60, 50, K, 600, True, K == 1022, False, 2, seed=4)
+    wi = D.work_info()
+    assert wi["w_layout"] == layout and wi["ld"] >= K, wi
+    M.iterate(2); D.iterate(2)
+    for w in compare_states(True, K == 1022):
+        assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
+
+
 def test_default_packs_k100_rows_and_refuses_what_it_cannot_hold(orc):
     """K = 100: 104 columns x 59 bits = 768 bytes, six lines instead of seven, chosen by default.
     A W entry below 2^-127 of its row maximum (an Elog spread above 88 inside a row -- no HPF
