@@ -599,6 +599,33 @@ def test_lossless_packed_rows_and_plain_rows_both_match_the_oracle(orc, monkeypa
     assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
 
 
+@pytest.mark.parametrize("K,bias", [(100, False), (50, True), (202, False)])
+def test_packed_rows_are_lossless_against_plain_rows(orc, monkeypatch, K, bias):
+    """The 59-bit packing drops only bits that carry nothing: a packed run and a plain-row run of
+    the same problem differ by the summation order inside a row alone (the lane <-> column map is
+    different) -- 1e-13 after six sweeps, where the lossy 48-bit mode is five orders away."""
+    from hgaprec_amd.capi import Hpf
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+    monkeypatch.setenv("HPF_W_PACK", "1")
+    n, m = 400, 300
+    rowptr, col, val = make_problem(n, m, 12000, 5)
+    M = orc.Model(n, m, K, True, bias, False)
+    M.set_csr(rowptr, col, val); M.initialize(5)
+    runs = {}
+    for ws in (0, 3, 2):
+        D = Hpf(n, m, K, hier=True, bias=bias, w_storage=ws)
+        D.upload_csr(rowptr, col, val)
+        copy_state(M, D, True, bias)
+        D.iterate(6)
+        runs[ws] = (D.work_info()["w_layout"], [D.get_state(w) for w in ("THETA_E", "BETA_E", "XI_E", "ETA_E")])
+        D.close()
+    assert [runs[ws][0] for ws in (0, 3, 2)] == [3, 0, 2]
+    lossless = max(rel_err(a, b) for a, b in zip(runs[0][1], runs[3][1]))
+    lossy = max(rel_err(a, b) for a, b in zip(runs[2][1], runs[3][1]))
+    assert lossless < 1e-13, lossless
+    assert lossy > 1e-12, lossy                      # the 48-bit rounding is visible at once; the packing is not
+
+
 @pytest.mark.parametrize("K,layout", [(900, 3), (1000, 0), (1022, 0)])
 def test_widest_rows_pack_when_the_sweep_has_a_shape_for_them(orc, K, layout):
     """K near HPF_MAX_COLUMNS: 900 columns pack (64 lanes x 15 = 960 columns, 56 lines instead of 64);
