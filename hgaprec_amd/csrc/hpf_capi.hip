@@ -1702,7 +1702,7 @@ void fill_snap_header(hpf_handle *h, SnapHeader *hd)
   memset(hd, 0, sizeof *hd);
   memcpy(hd->magic, "HPFSNAP2", 8);
   hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
-  hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->cfg.w_storage; hd->iterations = h->iterations;
+  hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->cfg.w_storage | ((uint32_t)h->wl << 8); hd->iterations = h->iterations;   // storage mode and the row layout in use
   hd->n_users_total = h->cfg.n_users_total; hd->rank = h->cfg.rank; hd->n_ranks = h->cfg.n_ranks;
   hd->novb = h->jacobi ? 1u : 0u; hd->nnz = h->have_csr ? h->nnz : 0;
   hd->s_prior = h->cfg.s_prior; hd->r_prior = h->cfg.r_prior;
@@ -1752,7 +1752,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
   // ---- everything is validated before the handle is touched: a rejected blob leaves it as it was
   SnapHeader hd; memcpy(&hd, host, sizeof hd);
   if (memcmp(hd.magic, "HPFSNAP2", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
-      hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != h->cfg.w_storage) {
+      hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (h->cfg.w_storage | ((uint32_t)h->wl << 8))) {
     h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
   }
   if (hd.s_prior != h->cfg.s_prior || hd.r_prior != h->cfg.r_prior || hd.n_users_total != h->cfg.n_users_total ||
