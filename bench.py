@@ -422,6 +422,13 @@ def main():
         self_check = {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
     ab = D.algorithmic_bytes()
     wi = D.work_info()
+    # the ceiling of each phi pass's ACCESS PATTERN on this GPU, measured now: the same work list,
+    # index stream and rows with the arithmetic taken out (hpf_gather_only).  Outside the timed region.
+    gather_only = None
+    try:
+        gather_only = {"phi_user": D.gather_only_ms(0, 3), "phi_item": D.gather_only_ms(1, 3)}
+    except Exception as ex:
+        gather_only = {"error": str(ex)}
 
     handover = {"generate_s": round(t_gen, 3), "upload_csr_device_s": round(t_upload, 3),
                 "set_state_device_s": round(t_state, 3)}
@@ -497,9 +504,11 @@ def main():
 
         per_kernel = None if graph else {
             "phi_item": {"algorithmic_bytes": ab["phi_item"], "ms": round(tm["phi_item_ms"], 4),
+                         "gather_only_ms": (gather_only or {}).get("phi_item"),
                          "GBps": gbs(ab["phi_item"], tm["phi_item_ms"]),
                          "note": "gathers rows of the user matrix (>> Infinity Cache): L2-miss fills from HBM"},
             "phi_user": {"algorithmic_bytes": ab["phi_user"], "ms": round(tm["phi_user_ms"], 4),
+                         "gather_only_ms": (gather_only or {}).get("phi_user"),
                          "GBps": gbs(ab["phi_user"], tm["phi_user_ms"]),
                          "note": "CACHE-INCLUSIVE: its gathers of item rows are largely served by L2 / Infinity "
                                  "Cache, so this figure may exceed the HBM peak; it is not an HBM rate"},
@@ -548,6 +557,10 @@ def main():
                 "hbm_only_source": hbm_only_note if hbm_only else "no DRAM-side counter in rocprofv3 -L on gfx950; "
                                    "no whole-C3 profile of this kernel source in profiles/traffic.json",
                 "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
+                # the same pass with the arithmetic taken out: what the memory system needs for its
+                # gathers alone.  frac_of_gather_only = that time / the pass's time
+                "gather_only_ms": (gather_only or {}).get(kern),
+                "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
                 # rows of W as stored: plain fp64 (8 B per element) or the LOSSLESS 59-bit packing the
                 # library picks where it saves a 128-byte line per row; the algorithmic bytes above
                 # use the stored element size, so they never exceed what has to move

@@ -33,7 +33,7 @@ EXPORTS = [
     "hpf_upload_csr", "hpf_set_state", "hpf_get_state", "hpf_iterate",
     "hpf_iterate_local", "hpf_iterate_local_items", "hpf_iterate_local_users",
     "hpf_iterate_local_phi", "hpf_iterate_local_sweep", "hpf_exchange_buffer", "hpf_bind_exchange_buffer",
-    "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_last_timing",
+    "hpf_iterate_global", "hpf_heldout_ll", "hpf_synchronize", "hpf_gather_only", "hpf_last_timing",
     "hpf_mean_timing", "hpf_elbo", "hpf_scores", "hpf_rank_topn", "hpf_item_ranks",
     "hpf_comm_unique_id", "hpf_comm_init", "hpf_allreduce_items_begin", "hpf_allreduce_exchange", "hpf_exchange_read", "hpf_exchange_write",
     "hpf_algorithmic_bytes",
@@ -145,6 +145,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_exchange_read.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_exchange_write.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_synchronize.argtypes = [vp]
+    lib.hpf_gather_only.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
     lib.hpf_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -465,6 +466,12 @@ class Hpf:
     def restore(self, blob: np.ndarray):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._check(self.lib.hpf_snapshot_load(self._h, C.c_void_p(blob.ctypes.data), blob.size))
+
+    def gather_only_ms(self, side: int, reps: int = 3) -> float:
+        """mean time of a phi pass with the arithmetic taken out (0: user-major, 1: item-major)"""
+        ms = C.c_float(0.0)
+        self._check(self.lib.hpf_gather_only(self._h, int(side), int(reps), C.byref(ms)))
+        return float(ms.value)
 
     def work_info(self) -> dict:
         w = HpfWorkInfo()

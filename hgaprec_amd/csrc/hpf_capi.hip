@@ -345,6 +345,26 @@ bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_
   return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, blocks, st) : launch_phipk_g<codec_f48>(G, L, side, a, blocks, st);
 }
 
+template <int G>
+bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+{
+#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
+  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) }
+#undef GO
+  return false;
+}
+bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_gather_only_l<4>(L, a, sink, blocks, st);
+    case 8:  return launch_gather_only_l<8>(L, a, sink, blocks, st);
+    case 16: return launch_gather_only_l<16>(L, a, sink, blocks, st);
+    case 32: return launch_gather_only_l<32>(L, a, sink, blocks, st);
+    case 64: return launch_gather_only_l<64>(L, a, sink, blocks, st);
+  }
+  return false;
+}
+
 // surfaces a numerical breakdown the kernels flagged (synchronises the stream)
 int check_flags(hpf_handle *h)
 {
@@ -2112,6 +2132,43 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->w_layout = (uint32_t)h->wl;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
+}
+
+int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
+{
+  if (!h || !ms_out || reps < 1 || (side != 0 && side != 1)) return HPF_ERR_INVALID;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if (h->w32 || (h->wl == WL_PLAIN && h->phiV != 2)) { h->err = "gather-only probe: rows of 16-byte pieces only"; return HPF_ERR_UNSUPPORTED; }
+  int rc;
+  if ((rc = prepare_derived(h))) return rc;
+  Side &own = side ? h->it : h->u, &oth = side ? h->u : h->it;
+  PhiArgs a;
+  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
+  a.W_own = own.W; a.W_oth = oth.W; a.S_own = nullptr; a.partial = nullptr; a.flags = h->flags;
+  *ms_out = 0.0f;
+  if (!a.nseg) return HPF_OK;
+  uint32_t *sink = nullptr;
+  if ((rc = dalloc(h, &sink, 1))) return rc;
+  const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);      // warm-up
+  if (ok) {
+    e = hipEventRecord(e0, h->stream);
+    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / (float)reps;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  dfree(sink);
+  if (!ok) { h->err = "no gather-only kernel for this shape"; return HPF_ERR_UNSUPPORTED; }
+  if (e != hipSuccess) { h->err = std::string("gather-only probe: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+  return check_launch(h, "gather-only probe");
 }
 
 int hpf_synchronize(hpf_handle *h)

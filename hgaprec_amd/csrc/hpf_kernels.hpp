@@ -475,6 +475,80 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
+// ---------------------------------------------------------------------
+// Measurement only (hpf_gather_only): a phi pass with the arithmetic taken out.  Same work
+// list, same index stream, same rows, same two register sets -- the gathered pieces are folded
+// with XORs into one register and nothing is written.  Its time is what the memory system
+// needs for the pass's access pattern; bench.py prints it beside the pass (roofline block).
+// Rows of L 16-byte pieces per lane at stride G*16: the packed layouts and plain fp64 rows with
+// 16-byte loads (V = 2) alike.
+// ---------------------------------------------------------------------
+template <int G, int L>
+__global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *sink)
+{
+  constexpr int NG = 64 / G;
+  constexpr uint32_t ROWB = G * L * 16;
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G, q = lane / G;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
+  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
+  uint4 acc = {0u, 0u, 0u, 0u};
+  auto load_row = [&](uint4 (&d)[L], const unsigned char *base) {
+#pragma unroll
+    for (int t = 0; t < L; ++t) d[t] = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
+  };
+  auto fold = [&](const uint4 (&d)[L]) {
+#pragma unroll
+    for (int t = 0; t < L; ++t) { acc.x ^= d[t].x; acc.y ^= d[t].y; acc.z ^= d[t].z; acc.w ^= d[t].w; }
+  };
+  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+    const Seg sg = a.segs[s];
+    const uint32_t len = sg.len;
+    const int64_t start = sg.start;
+    { uint4 r[L]; load_row(r, W_own + (size_t)sg.row * ROWB); fold(r); }
+    if (len == 0) continue;
+    auto load_i = [&](uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
+    uint32_t cur_i = load_i((uint32_t)lane), nxt_i = load_i(64u + lane);
+    const uint32_t nb = (len + NG - 1) / NG;
+    uint4 xa[L], xb[L];
+    auto gather = [&](uint4 (&x)[L], uint32_t b) {
+      const int src = (int)((b % G) * NG) + q;
+      const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
+      load_row(x, W_oth + (size_t)in * ROWB);
+    };
+    auto next_chunk = [&](uint32_t b) {
+      cur_i = nxt_i;
+      nxt_i = load_i((b / G + 1) * 64u + lane);
+    };
+    gather(xa, 0);
+    if (nb > 1) gather(xb, 1);
+    uint32_t bb = 0;
+    for (; bb + 3 < nb; bb += 2) {
+      fold(xa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (((bb + 2) % G) == 0) next_chunk(bb + 2);
+      gather(xa, bb + 2);
+      fold(xb);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(xb, bb + 3);
+    }
+    fold(xa);
+    if (bb + 1 < nb) {
+      const bool third = bb + 2 < nb;
+      __builtin_amdgcn_sched_barrier(0);
+      if (third) {
+        if (((bb + 2) % G) == 0) next_chunk(bb + 2);
+        gather(xa, bb + 2);
+      }
+      fold(xb);
+      if (third) fold(xa);
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;      // keeps the loads alive
+}
+
 // long rows: S[row] = sum over its segments' partials, in segment order.
 // One wave per long row; a lane owns columns c and c + 64 at once and the slot
 // loop is unrolled 16-fold, so 32 independent loads are in flight per lane

@@ -306,6 +306,13 @@ typedef struct {
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 
+/* measurement: one phi pass with the arithmetic taken out -- same work list, index stream and
+ * rows, the gathered bytes only folded into a register, nothing written.  The mean time of
+ * `reps` launches (side 0: user-major pass, 1: item-major pass) is what the memory system needs
+ * for that access pattern: the ceiling bench.py prints beside the pass itself.  Does not touch
+ * the model state. */
+int  hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out);
+
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
 /* mean over the last n_last iterations (at most 64 are kept); synchronises */

@@ -626,6 +626,24 @@ def test_packed_rows_are_lossless_against_plain_rows(orc, monkeypatch, K, bias):
     assert lossy > 1e-12, lossy                      # the 48-bit rounding is visible at once; the packing is not
 
 
+@pytest.mark.parametrize("K,ws", [(100, 0), (100, 3), (100, 2), (50, 0)])
+def test_gather_only_probe_leaves_the_model_alone(orc, K, ws):
+    """hpf_gather_only: a phi pass with the arithmetic taken out (same work list, indices, rows), the
+    ceiling bench.py prints beside the pass.  It must run for packed and plain 16-byte-piece rows,
+    return a time, and change nothing."""
+    M, D = _run_pair(orc, 500, 400, K, 20000, True, False, False, 2, seed=6, w_storage=ws)
+    D.iterate(1)
+    before = [D.get_state(w) for w in ("THETA_E", "BETA_E", "XI_E")]
+    for side in (0, 1):
+        assert D.gather_only_ms(side, 2) > 0.0
+    D.iterate(1)
+    M.iterate(2)
+    assert rel_err(D.get_state("BETA_E"), M.state("BETA_E")) < RTOL
+    E = _run_pair(orc, 500, 400, K, 20000, True, False, False, 2, seed=6, w_storage=ws)[1]
+    E.iterate(1)
+    assert all(np.array_equal(a, E.get_state(w)) for a, w in zip(before, ("THETA_E", "BETA_E", "XI_E")))
+
+
 @pytest.mark.parametrize("K,layout", [(900, 3), (1000, 0), (1022, 0)])
 def test_widest_rows_pack_when_the_sweep_has_a_shape_for_them(orc, K, layout):
     """K near HPF_MAX_COLUMNS: 900 columns pack (64 lanes x 15 = 960 columns, 56 lines instead of 64);

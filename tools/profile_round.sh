@@ -27,6 +27,11 @@ for v in base xcd; do
 done
 # 5. phi-pass time against the size of the gathered matrix (L2 / Infinity Cache / HBM)
 bash tools/size_sweep.sh $OUT/size > $OUT/size_sweep.txt 2>&1
+# 5b. what the machine gives a kernel that does nothing but random whole-row gathers
+if [ -x /opt/rocm/bin/hipcc ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/gather_ceiling tools/gather_ceiling.hip > /dev/null 2>&1
+  tools/gather_ceiling > $OUT/gather_ceiling.json 2> $OUT/gather_ceiling.log
+fi
 # 6. the other configs on one GPU; C1 and C4 WITH their CPU baseline
 python bench.py --config C1 --steps 20 --warmup 5 > $OUT/bench_c1.json 2> $OUT/bench_c1.log
 python bench.py --config C4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.log
