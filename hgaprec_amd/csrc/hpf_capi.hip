@@ -372,7 +372,7 @@ int check_flags(hpf_handle *h)
   HIPCHK(h, hipMemcpyAsync(&f, h->flags, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (f & 2u) {
-    h->err = "an entry of W fell below 2^-127 of its row maximum (Elog spread > 88 inside a row): the packed row layout "
+    h->err = "an entry of W fell below 2^-126 of its row maximum (Elog spread > 88 inside a row): the packed row layout "
              "cannot hold it; create the handle with w_storage = 3 (plain fp64 rows; `hgaprec -plain-rows`)";
     return HPF_ERR_STATE;
   }

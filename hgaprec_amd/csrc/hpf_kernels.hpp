@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 // (DESIGN.md section 6): the only lever left is 128-byte lines per gathered row.
 //
 //   p59  (the default whenever it shortens the row; LOSSLESS): every W is a positive fp64 in
-//        [2^-127, 2) or zero, so its sign bit and the four high exponent bits carry nothing:
+//        [2^-126, 2) or zero, so its sign bit and the four high exponent bits carry nothing:
 //        52 mantissa + 7 exponent bits = 59 bits per element.  K = 100: 104 columns in 768 bytes
-//        = six lines instead of seven.  A W below 2^-127 of its row maximum (an Elog spread
+//        = six lines instead of seven.  A W below 2^-126 of its row maximum (an Elog spread
 //        above 88 inside a row) cannot be stored: the sweep flushes it to zero and raises flag
 //        bit 1 (hpf_config.w_storage = 3 keeps plain fp64 rows for such states).
 //   f48  (hpf_config.w_storage = 2, opt-in, LOSSY): the top 48 bits of the fp64 value
@@ -324,12 +324,15 @@ __device__ __forceinline__ void packed_clear(uint32_t *buf, const PackedRow &pk,
   for (uint32_t d = li; d < pk.row_bytes / 4; d += nl) buf[d] = 0u;
 }
 
-// returns true when a nonzero w had to be flushed (below 2^-127)
+// returns true when a nonzero w had to be flushed (below 2^-126)
 __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
 {
   const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
   const uint32_t hi = (uint32_t)__double2hiint(w), lo = (uint32_t)__double2loint(w);
-  const bool tiny = hi < 0x38100000u;                     // exponent field below 897 (or zero / negative zero)
+  // representable: exponent field 897..1023, i.e. 2^-126 <= w < 2.  Anything else -- zero, a smaller
+  // value, and what a valid state never holds: w >= 2, infinities, NaN, negative numbers -- is stored as
+  // the all-zero element; only an exact +0 does so without being reported
+  const bool tiny = hi < 0x38100000u || hi >= 0x40000000u;
   const uint32_t f = tiny ? 0u : hi - 0x38000000u;
   buf[packed_dword_index(pk, g, e)] = tiny ? 0u : lo;
   const uint32_t o = 27u * e, i = pk.E + o / 32u, sh = o % 32u;
@@ -337,7 +340,7 @@ __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint
     atomicOr(&buf[packed_dword_index(pk, g, i)], f << sh);
     if (sh > 5u) atomicOr(&buf[packed_dword_index(pk, g, i + 1)], f >> (32u - sh));
   }
-  return tiny && (w != 0.0);
+  return tiny && !(hi == 0u && lo == 0u);
 }
 
 __device__ __forceinline__ void f48_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
@@ -695,7 +698,7 @@ struct SweepArgs {
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
   PackedRow     pk;         // packed W rows (WL != WL_PLAIN): the phi kernel's G, E, L and the row bytes
-  uint32_t     *flags;      // bit 1: a nonzero W below 2^-127 was flushed by the p59 layout
+  uint32_t     *flags;      // bit 1: a nonzero W below 2^-126 was flushed by the p59 layout
   int32_t       bias_col;   // column holding this side's bias (-1: none)
   int32_t       junk_col;   // column holding the other side's bias (-1: none)
   double        bias_rate_add;  // n_other_total for the bias column

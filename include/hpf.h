@@ -88,10 +88,10 @@ typedef struct {
                            /* 0: fp64, exact (default; the only mode chosen        */
                            /*    implicitly).  The library may PACK the rows       */
                            /*    losslessly (59 bits per element: every W is a     */
-                           /*    positive double in [2^-127, 2) or zero, so the    */
+                           /*    positive double in [2^-126, 2) or zero, so the    */
                            /*    sign and four exponent bits carry nothing) when   */
                            /*    that saves a 128-byte line per row -- K = 100:    */
-                           /*    six lines instead of seven.  A W below 2^-127 of  */
+                           /*    six lines instead of seven.  A W below 2^-126 of  */
                            /*    its row maximum (Elog spread > 88 inside a row)   */
                            /*    cannot be packed: HPF_ERR_STATE, use 3.           */
                            /* 3: fp64 in plain rows, never packed.                 */

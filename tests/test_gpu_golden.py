@@ -61,7 +61,7 @@ def test_softmax_golden_through_phi_passes(width, cases, rows):
     item-major pass the same numbers in beta's.
     rows = "plain": fp64 rows (w_storage = 3), every vector.  rows = "default": what the library
     picks by itself -- from K = 100 on the lossless 59-bit packing, which holds entries down to
-    2^-127 of the row maximum: the vectors whose spread stays below 80 (the others are refused
+    2^-126 of the row maximum: the vectors whose spread stays below 80 (the others are refused
     by that layout, tests/test_gpu_parity.py)."""
     ws = 3 if rows == "plain" else 0
     if rows == "default":

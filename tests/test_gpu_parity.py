@@ -659,7 +659,7 @@ def test_widest_rows_pack_when_the_sweep_has_a_shape_for_them(orc, K, layout):
 
 def test_default_packs_k100_rows_and_refuses_what_it_cannot_hold(orc):
     """K = 100: 104 columns x 59 bits = 768 bytes, six lines instead of seven, chosen by default.
-    A W entry below 2^-127 of its row maximum (an Elog spread above 88 inside a row -- no HPF
+    A W entry below 2^-126 of its row maximum (an Elog spread above 88 inside a row -- no HPF
     state has one) cannot be packed: the iteration reports it instead of dropping it silently;
     plain rows (w_storage = 3) take such a state."""
     from hgaprec_amd.capi import Hpf, HpfError
@@ -670,7 +670,7 @@ def test_default_packs_k100_rows_and_refuses_what_it_cannot_hold(orc):
     D.iterate(2); M.iterate(2)
     assert rel_err(D.get_state("BETA_E"), M.state("BETA_E")) < RTOL
     el = D.get_state("THETA_ELOG")
-    el[:, 0] -= 120.0                                   # exp(-120) = 7.7e-53 < 2^-127
+    el[:, 0] -= 120.0                                   # exp(-120) = 7.7e-53 < 2^-126
     for ws, ok in ((0, False), (3, True)):
         E = Hpf(n, m, K, hier=True, w_storage=ws)
         rowptr, col, val = make_problem(n, m, 4000, 3)
@@ -681,7 +681,7 @@ def test_default_packs_k100_rows_and_refuses_what_it_cannot_hold(orc):
             E.iterate(1); E.synchronize()
             assert np.isfinite(E.get_state("THETA_E")).all()
         else:
-            with pytest.raises(HpfError, match="2\\^-127"):
+            with pytest.raises(HpfError, match="2\\^-126"):
                 E.iterate(1); E.get_state("THETA_E")
         E.close()
 
