@@ -171,12 +171,12 @@ def test_world1_double_matches_oracle(bias):
     assert max(errs.values()) < 1e-10, errs
 
 
-@pytest.mark.parametrize("bias", [False, True])
-def test_world2_gloo_matches_oracle(bias):
+@pytest.mark.parametrize("world,bias", [(2, False), (2, True), (4, True)])
+def test_gloo_ranks_match_oracle(world, bias):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_rank, args=(r, 2, bias, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run_rank, args=(r, world, bias, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get() for _ in procs]
@@ -184,7 +184,8 @@ def test_world2_gloo_matches_oracle(bias):
         p.join(120)
         assert p.exitcode == 0
     ranges = sorted(r[2] for r in res)
-    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == N
+    assert ranges[0][0] == 0 and ranges[-1][1] == N
+    assert all(ranges[k][1] == ranges[k + 1][0] for k in range(world - 1))      # the user ranges tile [0, N)
     for _, errs, _ in res:
         assert max(errs.values()) < 1e-10, errs
 
