@@ -49,7 +49,7 @@ class HpfConfig(C.Structure):
         ("binary", C.c_uint32), ("n_users_total", C.c_uint32), ("device", C.c_int32),
         ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("w_storage", C.c_uint32),
         ("stream", C.c_void_p), ("s_prior", C.c_double), ("r_prior", C.c_double),
-        ("novb", C.c_uint32), ("reserved", C.c_uint32),
+        ("novb", C.c_uint32), ("tiling", C.c_uint32),
     ]
 
 
@@ -70,7 +70,7 @@ class HpfWorkInfo(C.Structure):
         ("item_segments", C.c_uint32), ("item_long_rows", C.c_uint32), ("item_huge_rows", C.c_uint32),
         ("phi_G", C.c_uint32), ("phi_R", C.c_uint32), ("phi_V", C.c_uint32),
         ("sweep_G", C.c_uint32), ("sweep_R", C.c_uint32), ("ld", C.c_uint32),
-        ("graph_replay", C.c_uint32), ("w_layout", C.c_uint32), ("reserved", C.c_uint32 * 2),
+        ("graph_replay", C.c_uint32), ("w_layout", C.c_uint32), ("tiles_user", C.c_uint32), ("tiles_item", C.c_uint32),
     ]
 
 
@@ -164,7 +164,7 @@ class Hpf:
 
     def __init__(self, n_users, n_items, K, hier=True, bias=False, binary=False,
                  device=0, stream=None, n_ranks=1, rank=0, n_users_total=0,
-                 s_prior=0.3, r_prior=0.3, w_storage=0, novb=False):
+                 s_prior=0.3, r_prior=0.3, w_storage=0, novb=False, tiling=0):
         self.lib = load_library()
         cfg = HpfConfig()
         cfg.struct_size = C.sizeof(HpfConfig)
@@ -176,6 +176,7 @@ class Hpf:
         cfg.s_prior, cfg.r_prior = float(s_prior), float(r_prior)
         cfg.w_storage = int(w_storage)
         cfg.novb = int(bool(novb))
+        cfg.tiling = int(tiling)             # 0: the library decides (tiled phi pass where it pays), 1: never
         self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(K)
         self.hier, self.bias, self.binary = bool(hier), bool(bias), bool(binary)
         self.device = int(device)            # the HIP ordinal every device pointer handed in must live on
@@ -476,7 +477,7 @@ class Hpf:
     def work_info(self) -> dict:
         w = HpfWorkInfo()
         self._check(self.lib.hpf_get_work_info(self._h, C.byref(w)))
-        return {f: getattr(w, f) for f, _ in HpfWorkInfo._fields_ if f != "reserved"}
+        return {f: getattr(w, f) for f, _ in HpfWorkInfo._fields_}
 
     def algorithmic_bytes(self) -> dict:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -74,6 +74,7 @@ int Env::parse(int argc, char **argv, bool echo, std::string *bad)
     else if (!strcmp(s, "-checkpoint")) { checkpoint_every = (uint32_t)atoi(next()); }   // extension
     else if (!strcmp(s, "-resume")) { resume = true; }                                 // extension
     else if (!strcmp(s, "-cache")) { data_cache = true; }                              // extension
+    else if (!strcmp(s, "-no-tiles")) { no_tiles = true; }       // extension: hpf_config.tiling = 1 (row-major work lists only)
     else if (!strcmp(s, "-plain-rows")) { plain_rows = true; }   // extension: hpf_config.w_storage = 3 (never pack the rows of W)
     else if (i > 0) {
       if (bad) *bad = s;

@@ -29,6 +29,7 @@ struct Env {
   // not part of the reference CLI: device ordinal for the HIP side, number of
   // GPUs (one process each) and how the per-iteration all-reduce is carried
   int device = 0; bool device_set = false;
+  bool no_tiles = false;                // -no-tiles: never tile the phi passes (hpf_config.tiling = 1)
   bool plain_rows = false;              // -plain-rows: keep W in plain fp64 rows (for states with an Elog spread > 88 inside a row)
   int ngpus = 1;
   std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)

@@ -139,6 +139,7 @@ struct Driver {
     cfg.n_users = hi - lo; cfg.n_items = m; cfg.K = k;
     cfg.hier = env.hier; cfg.bias = env.bias; cfg.binary = env.binary_data;
     cfg.novb = env.vb ? 0u : 1u;              // read by the library only where the reference reads it (vb_bias)
+    cfg.tiling = env.no_tiles ? 1u : 0u;
     cfg.w_storage = env.plain_rows ? 3u : 0u; // exact fp64 either way; 3 = never pack the rows
     cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = (uint32_t)comm.world; cfg.rank = (uint32_t)comm.rank;
     cfg.s_prior = 0.3; cfg.r_prior = 0.3;

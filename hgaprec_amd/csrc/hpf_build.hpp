@@ -172,6 +172,8 @@ struct RadixArgs {
   const uint32_t *keys_in;    // item ids in input order
   const uint32_t *users_in;   // NULL on the first pass
   const uint8_t  *vals_in;    // NULL with -binary-data
+  const uint32_t *extra_in;   // second 32-bit payload (the tile sort carries the gathered index here), or NULL
+  uint32_t       *extra_out;
   const int64_t  *rowptr;     // [n+1], first pass only
   uint32_t        n_rows;
   uint32_t       *keys_out;   // always written: colptr_from_sorted_kernel reads the last pass's keys
@@ -210,11 +212,12 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(RadixArgs a)
   for (int r = 0; r < RADIX_ROUNDS; ++r) {
     const uint64_t j = base + (uint64_t)r * 64 + lane;
     const bool ok = j < end;
-    uint32_t key = 0, user = 0, val = 0;
+    uint32_t key = 0, user = 0, val = 0, extra = 0;
     if (ok) {
       key = a.keys_in[j];
       user = a.users_in ? a.users_in[j] : row_of(a.rowptr, row_lo, row_hi, (int64_t)j);
       if (a.vals_in) val = a.vals_in[j];
+      if (a.extra_in) extra = a.extra_in[j];
     }
     const uint32_t d = (key >> a.shift) & (RADIX_DIGITS - 1);
     // lanes holding the same digit (inactive lanes match nobody)
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(RadixArgs a)
       if (a.keys_out) a.keys_out[p] = key;
       a.users_out[p] = user;
       if (a.vals_out) a.vals_out[p] = (uint8_t)val;
+      if (a.extra_out) a.extra_out[p] = extra;
     }
   }
 }
@@ -314,6 +318,169 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int64_t *ptr, uint3
       for (uint64_t g = 0; g < ng; ++g) {
         LongRow gr; gr.row = (uint32_t)(go + g); gr.first_slot = (uint32_t)(po + g * group_slots);
         gr.nslots = (uint32_t)((ns - g * group_slots < group_slots) ? ns - g * group_slots : group_slots); gr.pad = 0;
+        groups[go + g] = gr;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// Tiled phi pass (round 3): cache blocking of the gathered side.
+// A phi pass whose gathered rows sit in the XCD's own 4 MiB L2 runs three times faster than one
+// that has every row brought over the fabric (tools/l2probe.sh).  So the rows of the gathered
+// matrix are cut into tiles an L2 holds, and the nonzeros of the owner rows that meet every tile
+// often enough ("heavy" rows) are regrouped tile by tile: a work item is then a run of nonzeros of
+// one owner row inside one tile, the segments of a tile are handed to ONE XCD's workgroups in
+// order, and every gathered row crosses the fabric once per pass instead of once per nonzero.
+// The nonzeros of the light rows keep key 0: they stay row-major and are gathered as before.
+//
+//   tile_map_kernel       gathered row -> tile id (1 + row / T), or 1 / 0 for a "hot set" by degree
+//   tile_key_kernel       nonzero -> sort key: 0 for a light owner row, else the tile of its gathered row
+//   (radix sort on the key, stable: inside a key the order stays owner row, then as uploaded)
+//   seg_count / seg_emit  segments = maximal runs of one (key, owner row), cut at multiples of seg_max
+//   seg_len_kernel        lengths from the next segment's start; first segment of every key
+//   slot_plan / slot_fill per owner row: its segments in key order get consecutive partial slots
+//                         (rows with one segment write S themselves, rows with none are zeroed by
+//                         the combine), plus the LongRow lists of the combine kernels
+// All integer work, deterministic: no atomics decide an order.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_map_kernel(uint32_t *tilemap, uint32_t rows, uint32_t T,
+                                                       const int64_t *ptr, uint64_t hot_cutoff)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    tilemap[r] = hot_cutoff ? ((uint64_t)(ptr[r + 1] - ptr[r]) >= hot_cutoff ? 1u : 0u) : 1u + r / T;
+}
+
+// sum of the degrees >= cutoff and how many rows have one (two integers: order-free)
+__global__ __launch_bounds__(256) void deg_ge_kernel(const int64_t *ptr, uint32_t rows, uint64_t cutoff,
+                                                     unsigned long long *out /* [2]: rows, nonzeros */)
+{
+  unsigned long long c = 0, d = 0;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const uint64_t deg = (uint64_t)(ptr[r + 1] - ptr[r]);
+    if (deg >= cutoff) { c += 1; d += deg; }
+  }
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  if ((threadIdx.x & 63) == 0 && c) { atomicAdd(out, c); atomicAdd(out + 1, d); }
+}
+
+// a wave owns RADIX_TILE consecutive nonzeros (the owner row of each by bisection in the wave's window)
+__global__ __launch_bounds__(256) void tile_key_kernel(const int64_t *ptr, uint32_t rows, const uint32_t *idx, uint64_t nnz,
+                                                       const uint32_t *tilemap, uint64_t light_below, uint32_t *key,
+                                                       uint32_t *row_out)
+{
+  const int lane = threadIdx.x & 63;
+  const uint64_t wt = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t base = wt * RADIX_TILE;
+  if (base >= nnz) return;
+  const uint64_t end = (base + RADIX_TILE < nnz) ? base + RADIX_TILE : nnz;
+  const uint32_t row_lo = row_of(ptr, 0, rows - 1, (int64_t)base);
+  const uint32_t row_hi = row_of(ptr, row_lo, rows - 1, (int64_t)(end - 1));
+  for (uint64_t j = base + lane; j < end; j += 64) {
+    const uint32_t r = row_of(ptr, row_lo, row_hi, (int64_t)j);
+    const bool light = (uint64_t)(ptr[r + 1] - ptr[r]) < light_below;
+    key[j] = light ? 0u : tilemap[idx[j]];
+    row_out[j] = r;
+  }
+}
+
+__device__ __forceinline__ bool seg_starts_at(const uint32_t *key, const uint32_t *row, uint64_t j, uint32_t seg_max)
+{
+  return j == 0 || key[j] != key[j - 1] || row[j] != row[j - 1] || (j % seg_max) == 0;
+}
+
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *key, const uint32_t *row, uint64_t nnz,
+                                                        uint32_t seg_max, uint64_t *cnt)
+{
+  const int lane = threadIdx.x & 63;
+  const uint64_t wt = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t base = wt * RADIX_TILE;
+  if (base >= nnz) return;
+  const uint64_t end = (base + RADIX_TILE < nnz) ? base + RADIX_TILE : nnz;
+  uint32_t c = 0;
+  for (uint64_t j = base + lane; j < end; j += 64) c += seg_starts_at(key, row, j, seg_max) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) cnt[wt] = c;
+}
+
+__global__ __launch_bounds__(256) void seg_emit_kernel(const uint32_t *key, const uint32_t *row, uint64_t nnz,
+                                                       uint32_t seg_max, const uint64_t *off, Seg *segs,
+                                                       uint32_t *seg_row, uint32_t *seg_key)
+{
+  const int lane = threadIdx.x & 63;
+  const uint64_t wt = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t base = wt * RADIX_TILE;
+  if (base >= nnz) return;
+  const uint64_t end = (base + RADIX_TILE < nnz) ? base + RADIX_TILE : nnz;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint64_t next = off[wt];
+  for (uint64_t j0 = base; j0 < end; j0 += 64) {
+    const uint64_t j = j0 + lane;
+    const bool st = j < end && seg_starts_at(key, row, j, seg_max);
+    const uint64_t m = __ballot(st);
+    if (st) {
+      const uint64_t s = next + (uint64_t)__popcll(m & lt);
+      Seg sg; sg.start = (int64_t)j; sg.row = row[j]; sg.len = 0; sg.pslot = -1; sg.pad = 0;
+      segs[s] = sg;
+      seg_row[s] = sg.row;
+      seg_key[s] = key[j];
+    }
+    next += (uint64_t)__popcll(m);
+  }
+}
+
+// first_seg[k] = first segment of key k (preset to 0xffffffff: the key has none)
+__global__ __launch_bounds__(256) void seg_len_kernel(Seg *segs, uint32_t nseg, uint64_t nnz, const uint32_t *seg_key,
+                                                      uint32_t *first_seg)
+{
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+    const int64_t e = (s + 1 < nseg) ? segs[s + 1].start : (int64_t)nnz;
+    segs[s].len = (uint32_t)(e - segs[s].start);
+    if (s == 0 || seg_key[s] != seg_key[s - 1]) first_seg[seg_key[s]] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *v, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+
+// segptr: [rows + 1] offsets into the row-sorted segment list
+__global__ __launch_bounds__(256) void slot_plan_kernel(const int64_t *segptr, uint32_t rows, uint32_t huge_slots,
+                                                        uint32_t group_slots, SegPlan p)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const uint64_t cnt = (uint64_t)(segptr[r + 1] - segptr[r]);
+    const bool combined = cnt != 1;                        // none: the combine zeroes the row
+    const bool is_huge = cnt > huge_slots;
+    p.nseg[r] = cnt;
+    p.nslot[r] = combined ? cnt : 0;
+    p.nlong[r] = (combined && !is_huge) ? 1 : 0;
+    p.nhuge[r] = is_huge ? 1 : 0;
+    p.ngroup[r] = is_huge ? (cnt + group_slots - 1) / group_slots : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void slot_fill_kernel(const int64_t *segptr, uint32_t rows, uint32_t huge_slots,
+                                                        uint32_t group_slots, SegPlan off, const uint32_t *seg_list,
+                                                        Seg *segs, LongRow *longs, LongRow *huges, LongRow *groups)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const int64_t a = segptr[r];
+    const uint64_t cnt = (uint64_t)(segptr[r + 1] - a);
+    if (cnt == 1) { segs[seg_list[a]].pslot = -1; continue; }
+    const uint64_t po = off.nslot[r];
+    for (uint64_t k = 0; k < cnt; ++k) segs[seg_list[a + (int64_t)k]].pslot = (int32_t)(po + k);
+    if (cnt <= huge_slots) {
+      LongRow lr; lr.row = r; lr.first_slot = (uint32_t)po; lr.nslots = (uint32_t)cnt; lr.pad = 0;
+      longs[off.nlong[r]] = lr;
+    } else {
+      const uint64_t go = off.ngroup[r], ng = (cnt + group_slots - 1) / group_slots;
+      LongRow top; top.row = r; top.first_slot = (uint32_t)go; top.nslots = (uint32_t)ng; top.pad = 0;
+      huges[off.nhuge[r]] = top;
+      for (uint64_t g = 0; g < ng; ++g) {
+        LongRow gr; gr.row = (uint32_t)(go + g); gr.first_slot = (uint32_t)(po + g * group_slots);
+        gr.nslots = (uint32_t)((cnt - g * group_slots < group_slots) ? cnt - g * group_slots : group_slots); gr.pad = 0;
         groups[go + g] = gr;
       }
     }

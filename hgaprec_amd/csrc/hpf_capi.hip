@@ -54,6 +54,13 @@ struct Side {
   LongRow *hugerows = nullptr; uint32_t nhuge = 0;
   double *partial2 = nullptr; uint32_t npartial2 = 0;
   uint32_t *idx = nullptr; uint8_t *val = nullptr;
+  // tiled pass (hpf_build.hpp): the nonzeros regrouped by (tile of the gathered row, owner row); segs then
+  // index p_idx / p_val, and workgroup b takes the segments chunks[b]
+  uint32_t *p_idx = nullptr; uint8_t *p_val = nullptr;
+  uint2 *chunks = nullptr; uint32_t nchunk_blocks = 0;
+  uint32_t tiles = 0, tile_rows = 0; uint64_t tiled_nnz = 0, light_below = 0;
+  const uint32_t *pass_idx() const { return p_idx ? p_idx : idx; }
+  const uint8_t *pass_val() const { return p_idx ? p_val : val; }
   int32_t bias_col = -1, junk_col = -1;
   double bias_rate_add = 0.0;
   uint32_t sweep_blocks = 0;
@@ -107,6 +114,14 @@ struct hpf_handle {
   uint32_t sweep_blocks_max = 2048;     // 8 waves per SIMD (HPF_SWEEP_BLOCKS); 1024 -> 2048: C2 user sweep 0.587 -> 0.544 ms
   uint32_t seg_max = 512;
   uint32_t huge_slots = 256, group_slots = 64;  // two-level combine above huge_slots segments (HPF_HUGE_SLOTS)
+  // tiled pass: 2 auto, 0 never, 1 forced with every row regrouped (HPF_TILE); bytes of gathered rows per tile
+  // (HPF_TILE_BYTES), segments per workgroup (HPF_TILE_CHUNK), the mean run a heavy row must reach in a
+  // tile (HPF_TILE_RUN), the share of the nonzeros the heavy rows must hold (HPF_TILE_SHARE, per cent)
+  // order of an XCD's queue (HPF_TILE_ORDER): 1 = the row-major rest in front on the even XCDs and behind on the
+  // odd ones, so that half the chip pulls over the fabric while the other half runs from its L2 (C2 item pass
+  // 4.39 ms; 0 = in front everywhere 4.75; 2 = dealt between the tiles 4.58)
+  int tile_order = 1;
+  int tile_mode = 2; uint64_t tile_bytes = 3u << 20; uint32_t tile_chunk = 8, tile_min_run = 16; double tile_min_share = 0.15;
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
@@ -206,6 +221,7 @@ void free_side(Side &s, bool S_external)
   dfree(s.rate_set); dfree(s.prior_shape_set); dfree(s.prior_elog_set);
   dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
   dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
+  dfree(s.p_idx); dfree(s.p_val); dfree(s.chunks);
   s = Side();
 }
 
@@ -620,6 +636,9 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
   dfree(s.partial); dfree(s.partial2);
   s.partial = nullptr; s.partial2 = nullptr;
   s.npartial = 0; s.npartial2 = 0;
+  dfree(s.p_idx); dfree(s.p_val); dfree(s.chunks);
+  s.p_idx = nullptr; s.p_val = nullptr; s.chunks = nullptr;
+  s.nchunk_blocks = 0; s.tiles = 0; s.tile_rows = 0; s.tiled_nnz = 0; s.light_below = 0;
   if (rows == 0) return HPF_OK;
   int rc = HPF_OK;
   uint64_t *cnt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -655,6 +674,252 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
   } while (0);
   for (int k = 0; k < 5; ++k) dfree(cnt[k]);
   dfree(bad);
+  return rc;
+}
+
+// ---- stable LSD radix sort of n records on the low `bits` bits of a 32-bit key, carrying a 32-bit
+// payload u (NULL at the start: the row of the record, by bisection in rowptr), an optional second
+// one x, and an optional byte v.  Buffers: the pass p writes set p & 1 of (K, U, X, V); *res = the
+// set that holds the result.  in_* are only read.
+struct SortSets { uint32_t *K[2], *U[2], *X[2]; uint8_t *V[2]; };
+int radix_sort_records(hpf_handle *h, uint64_t n, uint32_t bits, const uint32_t *in_k, const uint32_t *in_u,
+                       const uint32_t *in_x, const uint8_t *in_v, const int64_t *rowptr, uint32_t n_rows,
+                       const SortSets &b, int *res)
+{
+  const uint32_t P = std::max<uint32_t>(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
+  const uint64_t ntiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+  const uint32_t nblk = (uint32_t)((ntiles + 3) / 4);
+  uint64_t *counts = nullptr; uint32_t *bad = nullptr; int rc;
+  if ((rc = dalloc(h, &counts, (size_t)ntiles * RADIX_DIGITS)) || (rc = dalloc(h, &bad, 1))) { dfree(counts); dfree(bad); return rc; }
+  for (uint32_t p = 0; p < P && !rc; ++p) {
+    const int o = (int)(p & 1), i = o ^ 1;
+    RadixArgs a;
+    a.keys_in = p == 0 ? in_k : b.K[i];
+    a.users_in = p == 0 ? in_u : b.U[i];
+    a.extra_in = p == 0 ? in_x : b.X[i];
+    a.vals_in = p == 0 ? in_v : (in_v ? b.V[i] : nullptr);
+    a.rowptr = rowptr; a.n_rows = n_rows;
+    a.keys_out = b.K[o]; a.users_out = b.U[o];
+    a.extra_out = in_x ? b.X[o] : nullptr;
+    a.vals_out = in_v ? b.V[o] : nullptr;
+    a.offsets = counts; a.nnz = n; a.ntiles = ntiles; a.shift = p * RADIX_BITS;
+    hipLaunchKernelGGL(radix_count_kernel, dim3(nblk), dim3(256), 0, h->stream, a.keys_in, n, a.shift, ntiles, counts,
+                       0xffffffffu, bad);
+    if ((rc = check_launch(h, "radix_count_kernel"))) break;
+    if ((rc = device_scan<uint64_t>(h, counts, ntiles * RADIX_DIGITS, counts, false))) break;
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(256), 0, h->stream, a);
+    rc = check_launch(h, "radix_scatter_kernel");
+  }
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "record sort failed on the device"; rc = HPF_ERR_HIP; }
+  dfree(counts); dfree(bad);
+  *res = (int)((P - 1) & 1);
+  return rc;
+}
+
+uint32_t bits_for(uint64_t count) { uint32_t b = 0; while (b < 32 && ((uint64_t)1 << b) < count) ++b; return std::max<uint32_t>(b, 1); }
+
+// Tiled work list of one side (hpf_build.hpp "Tiled phi pass").  Called after
+// device_side_work: when the policy finds the side worth tiling, the plain work list is replaced.
+//   ptr       the side's own row pointers (rows + 1), idx / val its nonzeros in row order
+//   ptr_oth   row pointers of the gathered side (rows_oth + 1): degrees for the hot-set policy
+// Policy (auto):  the gathered matrix must be larger than twice a tile.
+//   "ranges"  tiles of T consecutive gathered rows; owner rows with at least tiles * min_run nonzeros are
+//             heavy (their nonzeros are regrouped), taken when those hold >= 15 % of the nonzeros
+// Forced by HPF_TILE (experimental knob): 0 never, 1 ranges whenever there are two tiles.
+int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_oth, uint64_t nnz, size_t row_bytes)
+{
+  if (h->tile_mode == 0 || h->cfg.tiling == 1 || nnz == 0 || s.rows == 0 || nnz >= (1ull << 32)) return HPF_OK;
+  const uint32_t T = (uint32_t)std::max<uint64_t>(h->tile_bytes / row_bytes, 1);
+  const uint32_t tiles = (rows_oth + T - 1) / T;
+  if (tiles < 2 || tiles > 65534) return HPF_OK;
+  if (h->tile_mode == 2 && (uint64_t)rows_oth * row_bytes < 2 * h->tile_bytes + h->tile_bytes / 2) return HPF_OK;
+  int rc = HPF_OK;
+  uint64_t light_below = (uint64_t)tiles * h->tile_min_run;
+  if (h->tile_mode == 1) light_below = 0;                         // forced: every row is regrouped
+  unsigned long long *stat = nullptr;
+  uint64_t heavy_rows = 0, heavy_nnz = nnz;
+  if (light_below) {
+    if ((rc = dalloc(h, &stat, 2))) return rc;
+    hipLaunchKernelGGL(deg_ge_kernel, dim3(grid_for(s.rows)), dim3(256), 0, h->stream, ptr, s.rows, light_below, stat);
+    unsigned long long hv[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(hv, stat, 16, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(stat);
+    if (e != hipSuccess) { h->err = std::string("deg_ge_kernel: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
+    heavy_rows = hv[0]; heavy_nnz = hv[1];
+    if ((double)heavy_nnz < h->tile_min_share * (double)nnz) return HPF_OK;
+  }
+  (void)heavy_rows;
+  {                                                               // room for the temporaries (26 bytes per nonzero)?
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fr < 40.0 * (double)nnz + (double)(1ull << 30)) return HPF_OK;
+  }
+
+  const uint32_t nkeys = tiles + 1;
+  uint32_t *tilemap = nullptr, *first_seg = nullptr, *seg_row = nullptr, *seg_key = nullptr, *iota = nullptr;
+  uint64_t *cnt = nullptr, *pl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t *segptr = nullptr;
+  SortSets b = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  SortSets sb = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  uint32_t *key0 = nullptr, *row0 = nullptr;
+  Seg *segs = nullptr; LongRow *longs = nullptr, *huges = nullptr, *groups = nullptr;
+  double *partial = nullptr, *partial2 = nullptr; uint2 *chunks_dev = nullptr;
+  uint32_t *keep_idx = nullptr; uint8_t *keep_val = nullptr;
+  bool done = false;
+  do {
+    // ---- keys and the sort
+    if ((rc = dalloc(h, &tilemap, rows_oth)) || (rc = dalloc(h, &key0, (size_t)nnz)) || (rc = dalloc(h, &row0, (size_t)nnz))) break;
+    hipLaunchKernelGGL(tile_map_kernel, dim3(grid_for(rows_oth)), dim3(256), 0, h->stream, tilemap, rows_oth, T,
+                       (const int64_t *)nullptr, (uint64_t)0);
+    const uint64_t nwt = (nnz + RADIX_TILE - 1) / RADIX_TILE;
+    const uint32_t wblk = (uint32_t)((nwt + 3) / 4);
+    hipLaunchKernelGGL(tile_key_kernel, dim3(wblk), dim3(256), 0, h->stream, ptr, s.rows, s.idx, nnz, tilemap, light_below,
+                       key0, row0);
+    if ((rc = check_launch(h, "tile_key_kernel"))) break;
+    const uint32_t kbits = bits_for(nkeys), KP = (kbits + RADIX_BITS - 1) / RADIX_BITS;
+    for (int k = 0; k < (KP > 1 ? 2 : 1) && !rc; ++k) {
+      if ((rc = dalloc(h, &b.K[k], (size_t)nnz)) || (rc = dalloc(h, &b.U[k], (size_t)nnz)) || (rc = dalloc(h, &b.X[k], (size_t)nnz))) break;
+      if (s.val) rc = dalloc(h, &b.V[k], (size_t)nnz);
+    }
+    if (rc) break;
+    int r = 0;
+    if ((rc = radix_sort_records(h, nnz, kbits, key0, row0, s.idx, s.val, nullptr, 0, b, &r))) break;
+    dfree(key0); key0 = nullptr; dfree(row0); row0 = nullptr; dfree(tilemap); tilemap = nullptr;
+    const uint32_t *skey = b.K[r], *srow = b.U[r];
+    keep_idx = b.X[r]; keep_val = b.V[r]; b.X[r] = nullptr; b.V[r] = nullptr;
+    for (int k = 0; k < 2; ++k) if (k != r) { dfree(b.K[k]); dfree(b.U[k]); dfree(b.X[k]); dfree(b.V[k]); b.K[k] = b.U[k] = b.X[k] = nullptr; b.V[k] = nullptr; }
+
+    // ---- segments
+    if ((rc = dalloc(h, &cnt, (size_t)nwt + 1))) break;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(wblk), dim3(256), 0, h->stream, skey, srow, nnz, h->seg_max, cnt);
+    if ((rc = check_launch(h, "seg_count_kernel"))) break;
+    if ((rc = device_scan<uint64_t>(h, cnt, nwt, cnt, true))) break;
+    uint64_t nseg64 = 0;
+    HIPCHK(h, hipMemcpyAsync(&nseg64, cnt + nwt, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (nseg64 == 0 || nseg64 > 0x7fffffffull) break;              // leaves the plain list in place
+    const uint32_t nseg = (uint32_t)nseg64;
+    if ((rc = dalloc(h, &segs, nseg)) || (rc = dalloc(h, &seg_row, nseg)) || (rc = dalloc(h, &seg_key, nseg)) ||
+        (rc = dalloc(h, &first_seg, nkeys))) break;
+    HIPCHK(h, hipMemsetAsync(first_seg, 0xff, (size_t)nkeys * 4, h->stream));
+    hipLaunchKernelGGL(seg_emit_kernel, dim3(wblk), dim3(256), 0, h->stream, skey, srow, nnz, h->seg_max, cnt, segs, seg_row, seg_key);
+    hipLaunchKernelGGL(seg_len_kernel, dim3(grid_for(nseg)), dim3(256), 0, h->stream, segs, nseg, nnz, seg_key, first_seg);
+    if ((rc = check_launch(h, "seg_emit_kernel"))) break;
+    std::vector<uint32_t> fs(nkeys);
+    HIPCHK(h, hipMemcpyAsync(fs.data(), first_seg, (size_t)nkeys * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    dfree(b.K[r]); dfree(b.U[r]); b.K[r] = b.U[r] = nullptr;
+    dfree(cnt); cnt = nullptr; dfree(seg_key); seg_key = nullptr; dfree(first_seg); first_seg = nullptr;
+
+    // ---- per owner row: its segments in key order -> partial slots and combine lists
+    if ((rc = dalloc(h, &iota, nseg))) break;
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(nseg)), dim3(256), 0, h->stream, iota, nseg);
+    for (int k = 0; k < 2 && !rc; ++k) { if ((rc = dalloc(h, &sb.K[k], nseg))) break; rc = dalloc(h, &sb.U[k], nseg); }
+    if (rc) break;
+    int sr = 0;
+    if ((rc = radix_sort_records(h, nseg, bits_for(s.rows), seg_row, iota, nullptr, nullptr, nullptr, 0, sb, &sr))) break;
+    if ((rc = dalloc(h, &segptr, (size_t)s.rows + 1))) break;
+    hipLaunchKernelGGL(colptr_from_sorted_kernel, dim3(grid_for(nseg)), dim3(256), 0, h->stream, sb.K[sr], (uint64_t)nseg, s.rows, segptr);
+    for (int k = 0; k < 5 && !rc; ++k) rc = dalloc(h, &pl[k], (size_t)s.rows + 1);
+    if (rc) break;
+    SegPlan plan = {pl[0], pl[1], pl[2], pl[3], pl[4]};
+    hipLaunchKernelGGL(slot_plan_kernel, dim3(grid_for(s.rows)), dim3(256), 0, h->stream, segptr, s.rows, h->huge_slots,
+                       h->group_slots, plan);
+    if ((rc = check_launch(h, "slot_plan_kernel"))) break;
+    for (int k = 0; k < 5 && !rc; ++k) rc = device_scan<uint64_t>(h, pl[k], s.rows, pl[k], true);
+    if (rc) break;
+    uint64_t tot[5];
+    for (int k = 0; k < 5; ++k) HIPCHK(h, hipMemcpyAsync(&tot[k], pl[k] + s.rows, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (tot[1] > 0x7fffffffull) break;
+    const uint32_t npartial = (uint32_t)tot[1], nlong = (uint32_t)tot[2], nhuge = (uint32_t)tot[3], ngroup = (uint32_t)tot[4];
+    if ((rc = dalloc(h, &longs, nlong))) break;
+    if (ngroup && ((rc = dalloc(h, &groups, ngroup)) || (rc = dalloc(h, &huges, nhuge)))) break;
+    hipLaunchKernelGGL(slot_fill_kernel, dim3(grid_for(s.rows)), dim3(256), 0, h->stream, segptr, s.rows, h->huge_slots,
+                       h->group_slots, plan, sb.U[sr], segs, longs, huges, groups);
+    if ((rc = check_launch(h, "slot_fill_kernel"))) break;
+    if ((rc = dalloc(h, &partial, (size_t)npartial * h->ld))) break;
+    if (ngroup && (rc = dalloc(h, &partial2, (size_t)ngroup * h->ld))) break;
+
+    // ---- chunks: eight queues, one per XCD (workgroup b runs on XCD b % 8).  A tile goes to the queue
+    // with the least work so far (its segments stay together and in order); with fewer than 32 tiles
+    // every tile is cut eight ways instead.  The row-major rest (key 0) is cut eight ways, in front.
+    std::vector<std::pair<uint32_t, uint32_t>> q[8], qt[8];
+    uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto key_end = [&](uint32_t k) { for (uint32_t j = k + 1; j < nkeys; ++j) if (fs[j] != 0xffffffffu) return fs[j]; return nseg; };
+    uint64_t tiled_segs = 0;
+    for (uint32_t k = 1; k < nkeys; ++k) {
+      if (fs[k] == 0xffffffffu) continue;
+      const uint32_t a0 = fs[k], a1 = key_end(k);
+      tiled_segs += a1 - a0;
+      if (tiles < 32) {
+        const uint64_t n = a1 - a0;
+        for (int x = 0; x < 8; ++x) {
+          const uint32_t lo = a0 + (uint32_t)(n * x / 8), hi = a0 + (uint32_t)(n * (x + 1) / 8);
+          if (hi > lo) { qt[x].push_back({lo, hi}); load[x] += hi - lo; }
+        }
+        continue;
+      }
+      int best = 0;
+      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      qt[best].push_back({a0, a1}); load[best] += a1 - a0;
+    }
+    // the row-major rest: an eighth per queue.  tile_order 0: in front of the tiles; 1: in front on the even
+    // XCDs, behind on the odd ones (half the chip pulls over the fabric while the other half runs from L2);
+    // 2: dealt between the tiles in equal pieces
+    const uint32_t c0 = fs[0] != 0xffffffffu ? fs[0] : 0u, c1 = fs[0] != 0xffffffffu ? key_end(0) : 0u;
+    for (int x = 0; x < 8; ++x) {
+      const uint64_t n = c1 - c0;
+      const uint32_t lo = c0 + (uint32_t)(n * x / 8), hi = c0 + (uint32_t)(n * (x + 1) / 8);
+      const bool front = h->tile_order == 0 || (h->tile_order == 1 && (x & 1) == 0);
+      if (h->tile_order == 2 && !qt[x].empty()) {
+        const uint64_t nt = qt[x].size(), nc = hi - lo;
+        for (uint64_t t = 0; t < nt; ++t) {
+          const uint32_t l2 = lo + (uint32_t)(nc * t / nt), h2 = lo + (uint32_t)(nc * (t + 1) / nt);
+          if (h2 > l2) q[x].push_back({l2, h2});
+          q[x].push_back(qt[x][t]);
+        }
+        continue;
+      }
+      if (front && hi > lo) q[x].push_back({lo, hi});
+      for (auto &rg : qt[x]) q[x].push_back(rg);
+      if (!front && hi > lo) q[x].push_back({lo, hi});
+    }
+    const uint32_t CH = std::max<uint32_t>(h->tile_chunk, 1);
+    std::vector<uint2> qc[8];
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) {
+      for (auto &rg : q[x])
+        for (uint32_t c0 = rg.first; c0 < rg.second; c0 += CH) qc[x].push_back(make_uint2(c0, std::min(c0 + CH, rg.second)));
+      longest = std::max(longest, qc[x].size());
+    }
+    if (longest == 0 || longest * 8 > 0x7fffffffull) break;
+    std::vector<uint2> chunks(longest * 8, make_uint2(0u, 0u));
+    for (int x = 0; x < 8; ++x) for (size_t j = 0; j < qc[x].size(); ++j) chunks[j * 8 + x] = qc[x][j];
+    if ((rc = dalloc(h, &chunks_dev, chunks.size()))) break;
+    HIPCHK(h, hipMemcpyAsync(chunks_dev, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+
+    // ---- swap the side's work list
+    dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows); dfree(s.partial); dfree(s.partial2);
+    s.segs = segs; s.nseg = nseg; segs = nullptr;
+    s.longrows = longs; s.nlong = nlong; longs = nullptr;
+    s.grouprows = groups; s.ngroup = ngroup; groups = nullptr;
+    s.hugerows = huges; s.nhuge = nhuge; huges = nullptr;
+    s.partial = partial; s.npartial = npartial; partial = nullptr;
+    s.partial2 = partial2; s.npartial2 = ngroup; partial2 = nullptr;
+    s.p_idx = keep_idx; s.p_val = keep_val; keep_idx = nullptr; keep_val = nullptr;
+    s.chunks = chunks_dev; s.nchunk_blocks = (uint32_t)chunks.size(); chunks_dev = nullptr;
+    s.tiles = tiles; s.tile_rows = T; s.tiled_nnz = heavy_nnz; s.light_below = light_below;
+    (void)tiled_segs;
+    done = true;
+  } while (0);
+  (void)done;
+  dfree(tilemap); dfree(first_seg); dfree(seg_row); dfree(seg_key); dfree(iota); dfree(cnt); dfree(segptr);
+  for (int k = 0; k < 5; ++k) dfree(pl[k]);
+  for (int k = 0; k < 2; ++k) { dfree(b.K[k]); dfree(b.U[k]); dfree(b.X[k]); dfree(b.V[k]); dfree(sb.K[k]); dfree(sb.U[k]); }
+  dfree(key0); dfree(row0); dfree(segs); dfree(longs); dfree(huges); dfree(groups); dfree(partial); dfree(partial2);
+  dfree(chunks_dev); dfree(keep_idx); dfree(keep_val);
   return rc;
 }
 
@@ -701,6 +966,7 @@ int build_csc_device(hpf_handle *h, uint32_t n, uint32_t m, uint64_t nnz)
       a.users_in = p == 0 ? nullptr : (out_final ? ut : h->it.idx);
       a.vals_in = !h->u.val ? nullptr : p == 0 ? h->u.val : (out_final ? vt : h->it.val);
       a.rowptr = h->rowptr_dev; a.n_rows = n;
+      a.extra_in = nullptr; a.extra_out = nullptr;
       a.keys_out = kbuf[p & 1];
       a.users_out = out_final ? h->it.idx : ut;
       a.vals_out = !h->u.val ? nullptr : (out_final ? h->it.val : vt);
@@ -819,10 +1085,11 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
   const int side = &own == &h->it ? 1 : 0;
   PhiArgs a;
-  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
+  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
+  a.chunks = own.chunks;
   if (a.nseg) {
-    const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+    const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
     if (!(h->wl != WL_PLAIN ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
                  : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream))) {
       h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
@@ -1113,7 +1380,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (h->cfg.s_prior <= 0) h->cfg.s_prior = 0.3;
   if (h->cfg.r_prior <= 0) h->cfg.r_prior = 0.3;
   h->w32 = cfg->w_storage == 1;          // only ever chosen by the caller's hpf_config
-  if (cfg->w_storage > 3) { delete h; return HPF_ERR_INVALID; }
+  if (cfg->w_storage > 3 || cfg->tiling > 1) { delete h; return HPF_ERR_INVALID; }
   h->K = cfg->K; h->C = C;
   // Tuning knobs are read from the environment ONLY under HPF_EXPERIMENTAL=1 (tests, tools/):
   // a stray variable must not change the layout or the summation order of a production run.
@@ -1230,6 +1497,12 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_OVERLAP")) h->overlap_sweep = atoi(e) != 0;
   if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
+  if (const char *e = knob("HPF_TILE")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_mode = v; }
+  if (const char *e = knob("HPF_TILE_ORDER")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_order = v; }
+  if (const char *e = knob("HPF_TILE_BYTES")) { long long v = atoll(e); if (v >= 1024) h->tile_bytes = (uint64_t)v; }
+  if (const char *e = knob("HPF_TILE_CHUNK")) { int v = atoi(e); if (v >= 1) h->tile_chunk = (uint32_t)v; }
+  if (const char *e = knob("HPF_TILE_RUN")) { int v = atoi(e); if (v >= 1) h->tile_min_run = (uint32_t)v; }
+  if (const char *e = knob("HPF_TILE_SHARE")) { int v = atoi(e); if (v >= 0 && v <= 100) h->tile_min_share = v / 100.0; }
   if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
@@ -1425,6 +1698,11 @@ static int finish_upload(hpf_handle *h, uint64_t nnz)
   if ((uint64_t)last != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
   if ((rc = device_side_work(h, h->u, h->rowptr_dev, n))) return rc;
   if ((rc = device_side_work(h, h->it, h->colptr_dev, m))) return rc;
+  {
+    const size_t rowb = h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : (size_t)h->ld * (h->w32 ? 4 : 8);
+    if ((rc = build_tiled_side(h, h->u, h->rowptr_dev, m, nnz, rowb))) return rc;     // the user pass gathers item rows
+    if ((rc = build_tiled_side(h, h->it, h->colptr_dev, n, nnz, rowb))) return rc;
+  }
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nnz = nnz; h->have_csr = true;
@@ -1937,7 +2215,7 @@ int hpf_elbo(hpf_handle *h, double *out)
     if (from_w && h->u.nseg) {
       const uint32_t ph = 0;
       ElboNnzWArgs a;
-      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.idx; a.val = h->u.val;
+      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.pass_idx(); a.val = h->u.pass_val();
       a.Wt = (const double *)h->u.W; a.Wb = (const double *)h->it.W; a.Et = h->u.E; a.Eb = h->it.E;
       a.Mt = Mt; a.Mb = Mb;
       a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K;
@@ -1947,7 +2225,7 @@ int hpf_elbo(hpf_handle *h, double *out)
     if (h->nnz && !from_w && h->u.nseg) {
       const uint32_t ph = 0;
       ElboNnzArgs a;
-      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.idx; a.val = h->u.val;
+      a.segs = h->u.segs; a.nseg = h->u.nseg; a.col = h->u.pass_idx(); a.val = h->u.pass_val();
       a.Lt = h->u.L; a.Lb = h->it.L; a.Et = h->u.E; a.Eb = h->it.E;
       a.partial = part + (size_t)ph * nb_nnz; a.ld = h->ld; a.K = h->K; a.C = h->C;
       a.ubias_col = h->cfg.bias ? h->u.bias_col : -1; a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
@@ -2130,6 +2408,7 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;
   out->ld = h->ld;
   out->w_layout = (uint32_t)h->wl;
+  out->tiles_user = h->u.tiles; out->tiles_item = h->it.tiles;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
 }
@@ -2143,13 +2422,14 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if ((rc = prepare_derived(h))) return rc;
   Side &own = side ? h->it : h->u, &oth = side ? h->u : h->it;
   PhiArgs a;
-  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.idx; a.val = own.val;
+  a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = nullptr; a.partial = nullptr; a.flags = h->flags;
+  a.chunks = own.chunks;
   *ms_out = 0.0f;
   if (!a.nseg) return HPF_OK;
   uint32_t *sink = nullptr;
   if ((rc = dalloc(h, &sink, 1))) return rc;
-  const uint32_t blocks = std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+  const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);

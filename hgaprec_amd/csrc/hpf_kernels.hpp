@@ -120,7 +120,29 @@ struct PhiArgs {
   double         *S_own;    // [rows_own x G*R*V]  raw sums (prior added by sweep)
   double         *partial;  // [npartial x G*R*V]
   uint32_t       *flags;    // bit 0 set when a live nonzero saw sum_k e_k == 0 (underflow of W)
+  // tiled pass (hpf_build.hpp): workgroup b works on the segments [chunks[b].x, chunks[b].y), one wave
+  // per segment in turn; the host lays the chunks out so that b % 8 -- the XCD a workgroup lands on --
+  // walks one tile after another.  NULL: the waves stride over the whole list.
+  const uint2    *chunks;
 };
+
+// the segments of this wave: first, end, stride
+struct SegRange { uint32_t s, end, step; };
+__device__ __forceinline__ SegRange seg_range(const PhiArgs &a)
+{
+  SegRange r;
+  if (a.chunks) {
+    const uint2 c = a.chunks[blockIdx.x];
+    r.s = __builtin_amdgcn_readfirstlane(c.x + (threadIdx.x >> 6));
+    r.end = __builtin_amdgcn_readfirstlane(c.y);
+    r.step = blockDim.x >> 6;
+  } else {
+    r.s = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    r.end = a.nseg;
+    r.step = (gridDim.x * blockDim.x) >> 6;
+  }
+  return r;
+}
 
 // one batch: x = the gathered rows (one nonzero per group), yf = its rating
 // factor as a float (0 for an empty slot)
@@ -156,13 +178,12 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
   const int lane = threadIdx.x & 63;
   const int g = lane % G;                // column lane
   const int q = lane / G;                // group = nonzero slot in a batch
-  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const SegRange sr = seg_range(a);
   const WT *W_own = (const WT *)a.W_own + (size_t)g * V;
   const WT *W_oth = (const WT *)a.W_oth + (size_t)g * V;
   bool underflow = false;
 
-  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
+  for (uint32_t s = sr.s; s < sr.end; s += sr.step) {
     const Seg sg = a.segs[s];            // wave-uniform: scalar loads
     const uint32_t len = sg.len;
     const int64_t start = sg.start;
@@ -390,8 +411,7 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
   constexpr uint32_t ROWB = G * L * 16;          // bytes of a W row
   const int lane = threadIdx.x & 63;
   const int g = lane % G, q = lane / G;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const SegRange sr = seg_range(a);
   const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
   const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
   bool underflow = false;
@@ -403,45 +423,66 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
       d[4 * t] = v.x; d[4 * t + 1] = v.y; d[4 * t + 2] = v.z; d[4 * t + 3] = v.w;
     }
   };
+  // 64 indices / ratings of a segment from offset o on (zeros past its end)
+  auto load_i = [&](int64_t start, uint32_t len, uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
+  auto load_y = [&](int64_t start, uint32_t len, uint32_t o) -> float {
+    if (o >= len) return 0.0f;
+    if (!a.val) return 1.0f;
+    const uint32_t y = a.val[start + o];
+    return (y > 1u) ? (float)y : 1.0f;
+  };
 
-  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
-    const Seg sg = a.segs[s];
+  // The wave's segments are one stream: the descriptor of the next segment and its first 64
+  // indices are fetched while the current one is worked on, so that a segment starts with its
+  // owner row and its first two batches of gathers in flight together -- one memory round trip
+  // instead of three in a row (descriptor, indices, rows).  Rows of fifty nonzeros (C2's users)
+  // and the runs of a tiled pass are a handful of batches long: the round trips were most of them.
+  if (sr.s >= sr.end) return;
+  Seg sgn = a.segs[sr.s];
+  uint32_t nxt_i = load_i(sgn.start, sgn.len, (uint32_t)lane);
+  float nxt_y = load_y(sgn.start, sgn.len, (uint32_t)lane);
+  for (uint32_t s = sr.s; s < sr.end; s += sr.step) {
+    const Seg sg = sgn;
+    const bool more = s + sr.step < sr.end;
+    if (more) sgn = a.segs[s + sr.step];
     const uint32_t len = sg.len;
     const int64_t start = sg.start;
+    uint32_t cur_i = nxt_i;
+    float cur_y = nxt_y;
+    const uint32_t nb = (len + NG - 1) / NG;
+    uint32_t xa[4 * L], xb[4 * L];
+    float ya = 0.0f, yb = 0.0f;
+    auto gather = [&](uint32_t (&x)[4 * L], float &y, uint32_t b) {
+      const int src = (int)((b % G) * NG) + q;
+      const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
+      y = __shfl(cur_y, src, 64);
+      load_row(x, W_oth + (size_t)in * ROWB);
+    };
+    // chunk c has become the current one: fetch the one after it -- of this segment, or the
+    // first one of the next segment
+    auto fetch_after = [&](uint32_t c) {
+      const uint32_t o = (c + 1) * 64u;
+      const bool same = o < len;                        // scalar selects, no branch: one masked load each
+      const int64_t st = same ? start : sgn.start;
+      const uint32_t ln = same ? len : (more ? sgn.len : 0u), of = same ? o : 0u;
+      nxt_i = load_i(st, ln, of + lane); nxt_y = load_y(st, ln, of + lane);
+    };
+    auto next_chunk = [&](uint32_t b) {
+      cur_i = nxt_i; cur_y = nxt_y;
+      fetch_after(b / G);
+    };
     double own[E], acc[E];
     {
       uint32_t r[4 * L];
       load_row(r, W_own + (size_t)sg.row * ROWB);
+      gather(xa, ya, 0);          // unconditional (a conditional gather costs copies and waits): past the
+      gather(xb, yb, 1);          // segment's end the index reads 0 -- row 0, loaded and never used
+      fetch_after(0);
 #pragma unroll
       for (int e = 0; e < E; ++e) { own[e] = Codec::get(r, e); acc[e] = 0.0; }
     }
     if (len > 0) {
-      auto load_i = [&](uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
-      auto load_y = [&](uint32_t o) -> float {
-        if (o >= len) return 0.0f;
-        if (!a.val) return 1.0f;
-        const uint32_t y = a.val[start + o];
-        return (y > 1u) ? (float)y : 1.0f;
-      };
-      uint32_t cur_i = load_i((uint32_t)lane), nxt_i = load_i(64u + lane);
-      float cur_y = load_y((uint32_t)lane), nxt_y = load_y(64u + lane);
-      const uint32_t nb = (len + NG - 1) / NG;
-      uint32_t xa[4 * L], xb[4 * L];
-      float ya, yb = 0.0f;
-      auto gather = [&](uint32_t (&x)[4 * L], float &y, uint32_t b) {
-        const int src = (int)((b % G) * NG) + q;
-        const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
-        y = __shfl(cur_y, src, 64);
-        load_row(x, W_oth + (size_t)in * ROWB);
-      };
-      auto next_chunk = [&](uint32_t b) {
-        cur_i = nxt_i; cur_y = nxt_y;
-        const uint32_t o = (b / G + 1) * 64u + lane;
-        nxt_i = load_i(o); nxt_y = load_y(o);
-      };
       // same schedule as phi_pass_kernel: two register sets, peeled tail
-      gather(xa, ya, 0);
-      if (nb > 1) gather(xb, yb, 1);
       uint32_t bb = 0;
       for (; bb + 3 < nb; bb += 2) {
         phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
@@ -493,8 +534,7 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
   constexpr uint32_t ROWB = G * L * 16;
   const int lane = threadIdx.x & 63;
   const int g = lane % G, q = lane / G;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const SegRange sr = seg_range(a);
   const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
   const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
   uint4 acc = {0u, 0u, 0u, 0u};
@@ -506,14 +546,17 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
 #pragma unroll
     for (int t = 0; t < L; ++t) { acc.x ^= d[t].x; acc.y ^= d[t].y; acc.z ^= d[t].z; acc.w ^= d[t].w; }
   };
-  for (uint32_t s = wave; s < a.nseg; s += nwaves) {
-    const Seg sg = a.segs[s];
+  auto load_i = [&](int64_t start, uint32_t len, uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
+  if (sr.s >= sr.end) return;
+  Seg sgn = a.segs[sr.s];                           // the pass's stream of segments (phi_pass_packed_kernel)
+  uint32_t nxt_i = load_i(sgn.start, sgn.len, (uint32_t)lane);
+  for (uint32_t s = sr.s; s < sr.end; s += sr.step) {
+    const Seg sg = sgn;
+    const bool more = s + sr.step < sr.end;
+    if (more) sgn = a.segs[s + sr.step];
     const uint32_t len = sg.len;
     const int64_t start = sg.start;
-    { uint4 r[L]; load_row(r, W_own + (size_t)sg.row * ROWB); fold(r); }
-    if (len == 0) continue;
-    auto load_i = [&](uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
-    uint32_t cur_i = load_i((uint32_t)lane), nxt_i = load_i(64u + lane);
+    uint32_t cur_i = nxt_i;
     const uint32_t nb = (len + NG - 1) / NG;
     uint4 xa[L], xb[L];
     auto gather = [&](uint4 (&x)[L], uint32_t b) {
@@ -521,12 +564,16 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
       const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
       load_row(x, W_oth + (size_t)in * ROWB);
     };
-    auto next_chunk = [&](uint32_t b) {
-      cur_i = nxt_i;
-      nxt_i = load_i((b / G + 1) * 64u + lane);
+    auto fetch_after = [&](uint32_t c) {
+      const uint32_t o = (c + 1) * 64u;
+      const bool same = o < len;
+      const int64_t st = same ? start : sgn.start;
+      const uint32_t ln = same ? len : (more ? sgn.len : 0u), of = same ? o : 0u;
+      nxt_i = load_i(st, ln, of + lane);
     };
-    gather(xa, 0);
-    if (nb > 1) gather(xb, 1);
+    auto next_chunk = [&](uint32_t b) { cur_i = nxt_i; fetch_after(b / G); };
+    { uint4 r[L]; load_row(r, W_own + (size_t)sg.row * ROWB); gather(xa, 0); gather(xb, 1); fetch_after(0); fold(r); }
+    if (len == 0) continue;
     uint32_t bb = 0;
     for (; bb + 3 < nb; bb += 2) {
       fold(xa);

@@ -113,7 +113,13 @@ typedef struct {
                            /* expectations before anything is swapped (the     */
                            /* item rate takes the old sum_u E[theta]).         */
                            /* n_ranks must be 1 in that mode.                  */
-  uint32_t reserved;
+  uint32_t tiling;         /* 0: the library decides per side whether the phi  */
+                           /* pass is tiled (cache blocking of the gathered    */
+                           /* rows, one tile per XCD L2) */
+                           /* 1: never -- row-major work lists only.  Tiling   */
+                           /* changes the ORDER in which a row's nonzeros are  */
+                           /* summed (same for every run of one build), not    */
+                           /* what is summed.                                  */
 } hpf_config;
 
 /* per-kernel device time, milliseconds, from hipEvents recorded on the
@@ -302,7 +308,7 @@ typedef struct {
   uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
   uint32_t w_layout;                 /* rows of W: 0 plain (phi_V elements per load), 3 packed 59-bit (lossless),  */
                                      /* 2 packed 48-bit (w_storage = 2); packed: phi_R = 16-byte pieces per lane   */
-  uint32_t reserved[2];
+  uint32_t tiles_user, tiles_item;   /* tiled phi pass: tiles of the gathered matrix (0: the side is row-major)   */
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 
