@@ -88,7 +88,7 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
 
 def kernels_sha():
     h = hashlib.sha256()
-    for f in ("hpf_kernels.hpp",):                    # the kernels' source: what the traffic was measured on
+    for f in ("hpf_kernels.hpp", "hpf_build.hpp"):    # the kernels and the work lists they walk: what the traffic was measured on
         h.update((ROOT / "hgaprec_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -96,7 +96,7 @@ def kernels_sha():
 def measured_traffic(config, kern):
     """HBM-side bytes per launch from the PMC passes kept in profiles/traffic.json
     (FETCH_SIZE x 2 + WRITE_SIZE, see profiles/README.md).  Only quoted when the
-    file was measured on THIS kernel source (sha of hpf_kernels.hpp)."""
+    file was measured on THIS kernel source (sha of hpf_kernels.hpp + hpf_build.hpp)."""
     tf = ROOT / "profiles" / "traffic.json"
     if not tf.exists():
         return None, "no profiles/traffic.json"
@@ -565,12 +565,19 @@ def main():
                 # library picks where it saves a 128-byte line per row; the algorithmic bytes above
                 # use the stored element size, so they never exceed what has to move
                 "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)"}.get(wi["w_layout"]),
+                # tiled pass: the nonzeros of the heavy rows are regrouped by 3 MiB tile of
+                # the gathered matrix and a tile's segments run on one XCD, out of its L2.  `achieved` stays
+                # ALGORITHMIC bytes / time (every gathered row counted once per nonzero), so with tiling it can
+                # pass the HBM peak: the tiled share of those bytes never crosses the fabric -- `traffic` shows it
+                "tiles": {"phi_item": wi["tiles_item"], "phi_user": wi["tiles_user"],
+                          "note": "0 = row-major pass; >0 = heavy rows regrouped by that many tiles of the gathered rows"},
                 "hbm_copy_measured_GBps": copy_gbs,
                 "per_kernel": per_kernel,
             },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
             "work": {k: wi[k] for k in ("user_segments", "item_segments", "user_long_rows", "item_long_rows",
-                                        "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R", "ld", "w_layout")},
+                                        "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R", "ld", "w_layout",
+                                        "tiles_user", "tiles_item")},
             "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
             # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user

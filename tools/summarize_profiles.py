@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def kernels_sha():
     h = hashlib.sha256()
-    for f in ("hpf_kernels.hpp",):                    # the kernels' source: what the traffic was measured on
+    for f in ("hpf_kernels.hpp", "hpf_build.hpp"):    # the kernels and the work lists they walk: what the traffic was measured on
         h.update((ROOT / "hgaprec_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
