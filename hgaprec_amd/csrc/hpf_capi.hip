@@ -121,7 +121,8 @@ struct hpf_handle {
   // odd ones, so that half the chip pulls over the fabric while the other half runs from its L2 (C2 item pass
   // 4.39 ms; 0 = in front everywhere 4.75; 2 = dealt between the tiles 4.58)
   int tile_order = 1;
-  int tile_mode = 2; uint64_t tile_bytes = 3u << 20; uint32_t tile_chunk = 8, tile_min_run = 16; double tile_min_share = 0.15;
+  int tile_sides = 3;                   // HPF_TILE_SIDES: bit 0 the user pass, bit 1 the item pass (experiments)
+  int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 8, tile_min_run = 16; double tile_min_share = 0.15;
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
@@ -728,13 +729,17 @@ uint32_t bits_for(uint64_t count) { uint32_t b = 0; while (b < 32 && ((uint64_t)
 // Forced by HPF_TILE (experimental knob): 0 never, 1 ranges whenever there are two tiles.
 int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_oth, uint64_t nnz, size_t row_bytes)
 {
+  if (!((h->tile_sides >> (&s == &h->it ? 1 : 0)) & 1)) return HPF_OK;
   if (h->tile_mode == 0 || h->cfg.tiling == 1 || nnz == 0 || s.rows == 0 || nnz >= (1ull << 32)) return HPF_OK;
   const uint32_t T = (uint32_t)std::max<uint64_t>(h->tile_bytes / row_bytes, 1);
   const uint32_t tiles = (rows_oth + T - 1) / T;
   if (tiles < 2 || tiles > 65534) return HPF_OK;
   if (h->tile_mode == 2 && (uint64_t)rows_oth * row_bytes < 2 * h->tile_bytes + h->tile_bytes / 2) return HPF_OK;
   int rc = HPF_OK;
-  uint64_t light_below = (uint64_t)tiles * h->tile_min_run;
+  // a gathered matrix of a few tiles is already served largely from L2 when the ratings are skewed (the popular
+  // rows stay resident): regrouping then pays only for rows that meet a tile many times (size sweep, m = 20 000:
+  // four tiles, user pass 3.19 ms row-major, 3.64 ms with runs of 16)
+  uint64_t light_below = (uint64_t)tiles * h->tile_min_run * (tiles < 8 ? 4u : 1u);
   if (h->tile_mode == 1) light_below = 0;                         // forced: every row is regrouped
   unsigned long long *stat = nullptr;
   uint64_t heavy_rows = 0, heavy_nnz = nnz;
@@ -1498,6 +1503,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = knob("HPF_TILE")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_mode = v; }
+  if (const char *e = knob("HPF_TILE_SIDES")) { int v = atoi(e); if (v >= 0 && v <= 3) h->tile_sides = v; }
   if (const char *e = knob("HPF_TILE_ORDER")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_order = v; }
   if (const char *e = knob("HPF_TILE_BYTES")) { long long v = atoll(e); if (v >= 1024) h->tile_bytes = (uint64_t)v; }
   if (const char *e = knob("HPF_TILE_CHUNK")) { int v = atoi(e); if (v >= 1) h->tile_chunk = (uint32_t)v; }

@@ -157,12 +157,12 @@ def test_tiled_with_empty_rows_and_empty_tiles(orc, tile_env):
 
 
 def test_automatic_policy_tiles_a_skewed_side_only(orc):
-    """No knobs: 3 MiB tiles.  40 000 users x 768 B = 29 MiB of gathered rows for the item pass and a
+    """No knobs: 4 MiB tiles.  60 000 users x 768 B = 44 MiB of gathered rows for the item pass and a
     handful of items holding most ratings -> the item side is tiled; the user pass gathers 2 000
     item rows (1.5 MiB: they fit an L2 as they are) -> row-major."""
     from hgaprec_amd.capi import Hpf
     from hgaprec_amd import synth
-    n, m, K, nnz = 40000, 2000, 100, 3_000_000
+    n, m, K, nnz = 60000, 2000, 100, 4_000_000
     rowptr, col, val = synth.generate(n, m, nnz, alpha_u=0.3, alpha_i=1.2, seed=4, device="cuda")
     M = orc.Model(n, m, K, True, False, False)
     M.set_csr(rowptr, col, val); M.initialize(4)
@@ -170,7 +170,7 @@ def test_automatic_policy_tiles_a_skewed_side_only(orc):
     D.upload_csr(rowptr, col, val)
     copy_state(M, D, True, False)
     wi = D.work_info()
-    assert wi["tiles_item"] >= 9 and wi["tiles_user"] == 0, wi
+    assert wi["tiles_item"] >= 8 and wi["tiles_user"] == 0, wi
     M.iterate(2); D.iterate(2)
     for w in compare_states(True, False):
         assert _err(w, D.get_state(w), M.state(w)) < RTOL, w

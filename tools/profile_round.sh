@@ -25,6 +25,14 @@ for v in base xcd; do
   rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/xcd_pmc_tcc_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_tcc_$v.log
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/xcd_pmc_fetch_$v -o p -- python tools/xcd_locality_probe.py $v 3 > /dev/null 2> $OUT/xcd_pmc_fetch_$v.log
 done
+# 4b. the tiled pass: where workgroups run, the same bench line with the tiles switched
+# off, and the L2 hit rate of the item pass either way; l2probe = a pass whose gathered rows fit one L2
+tools/xcc_probe 200000 2000 > $OUT/xcc_probe.json 2> $OUT/xcc_probe.log
+tools/xcc_probe 50000 20000 >> $OUT/xcc_probe.json 2>> $OUT/xcc_probe.log
+HPF_EXPERIMENTAL=1 HPF_TILE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_untiled.json 2> $OUT/bench_c2_untiled.log
+HPF_EXPERIMENTAL=1 HPF_TILE=0 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc_untiled -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_tcc_untiled.log
+HPF_EXPERIMENTAL=1 HPF_TILE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_untiled -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch_untiled.log
+bash tools/l2probe.sh > $OUT/l2probe.txt 2>&1
 # 5. phi-pass time against the size of the gathered matrix (L2 / Infinity Cache / HBM)
 bash tools/size_sweep.sh $OUT/size > $OUT/size_sweep.txt 2>&1
 # 5b. what the machine gives a kernel that does nothing but random whole-row gathers
@@ -36,6 +44,8 @@ fi
 python bench.py --config C1 --steps 20 --warmup 5 > $OUT/bench_c1.json 2> $OUT/bench_c1.log
 python bench.py --config C4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.log
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --host-handover > $OUT/bench_c3_full_1gpu.json 2> $OUT/bench_c3_full_1gpu.log
+HPF_EXPERIMENTAL=1 HPF_TILE=0 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c3_full_1gpu_untiled.json 2> $OUT/bench_c3_full_1gpu_untiled.log
+HPF_EXPERIMENTAL=1 HPF_TILE=0 python bench.py --config C4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c4_untiled.json 2> $OUT/bench_c4_untiled.log
 python bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_full_1gpu.json 2> $OUT/bench_c5_full_1gpu.log
 # 7. what one of 8 GPUs would hold of C3 (1.25M users x ALL 1M items, 1.25e8 nnz): the compute side of the 8-GPU estimate
 python bench.py --config C3 --n 1250000 --nnz 125000000 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c3_shard_like_1gpu.json 2> $OUT/bench_c3_shard_like_1gpu.log

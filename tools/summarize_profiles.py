@@ -55,7 +55,7 @@ def main():
             "derive_w", "repack_", "colsum_partial", "prior_update", "materialize_es")
     rows = []
     traffic = {}
-    passes = {p.name: counter_means(p) for p in src.glob("pmc_*") if p.is_dir()}
+    passes = {p.name: counter_means(p) for p in src.glob("pmc_*") if p.is_dir() and not p.name.endswith("_untiled")}
     merged = defaultdict(dict)
     for cm in passes.values():
         for k, cs in cm.items():
@@ -133,7 +133,36 @@ def main():
                         xcd.setdefault(v, {}).setdefault("pmc_" + side, {}).update({c: round(x[0], 1) for c, x in cs.items()})
     if xcd:
         (dst / "xcd_locality_probe.json").write_text(json.dumps(xcd, indent=1))
-    c3f = src / "bench_c3_full_1gpu.json"
+    # tiled against row-major item pass at C2: L2 requests and what crossed the fabric
+    til = {}
+    for label, suffix in (("tiled (default)", ""), ("row-major (HPF_TILE=0)", "_untiled")):
+        ent = {}
+        for d_ in (src / f"pmc_tcc_hit_sum_tcc_miss_sum{suffix}", src / f"pmc_tcc{suffix}", src / f"pmc_fetch_size{suffix}", src / f"pmc_fetch{suffix}"):
+            if not d_.is_dir():
+                continue
+            for k, cs in counter_means(d_).items():
+                if "phi_pass" in k and "f48" not in k and k.rstrip(">").endswith("1"):
+                    ent["kernel"] = k
+                    ent.update({c: round(x[0], 1) for c, x in cs.items()})
+        if "TCC_HIT_sum" in ent:
+            ent["L2_hit_rate"] = round(ent["TCC_HIT_sum"] / max(ent["TCC_HIT_sum"] + ent["TCC_MISS_sum"], 1.0), 4)
+        if "FETCH_SIZE" in ent:
+            ent["fabric_read_bytes"] = int(2 * ent["FETCH_SIZE"] * 1024)
+        bj2 = src / ("bench_c2_untiled.json" if suffix else "bench.json")
+        if bj2.exists() and bj2.read_text().strip():
+            try:
+                d2 = json.loads(bj2.read_text().strip().splitlines()[-1])
+                ent["phi_item_ms"] = d2["kernels_ms"]["phi_item_ms"]; ent["iteration_ms"] = d2["ms_per_step"]
+                ent["tiles_item"] = d2["work"].get("tiles_item")
+            except Exception:
+                pass
+        if ent:
+            til[label] = ent
+    if til:
+        (dst / "tiling_c2_item_pass.json").write_text(json.dumps(til, indent=1) + "\n")
+    c3f = src / "bench_c3_full_1gpu_untiled.json"
+    if not (c3f.exists() and c3f.read_text().strip()):
+        c3f = src / "bench_c3_full_1gpu.json"
     if traffic and c3f.exists() and c3f.read_text().strip():
         # the item pass where nothing it gathers is cache-resident (9 GB of user rows): algorithmic GB/s
         d3 = json.loads(c3f.read_text().strip().splitlines()[-1])
@@ -142,7 +171,7 @@ def main():
     if traffic:
         traffic["kernels_sha"] = kernels_sha()
         traffic["measured"] = (f"profiles/{tag}/pmc_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, bench.py --steps 3 "
-                               f"--warmup 1; hbm_only: profiles/{tag}/bench_c3_full_1gpu.json (whole C3 on one GPU, algorithmic bytes / time)")
+                               f"--warmup 1; hbm_only: profiles/{tag}/{c3f.name} (whole C3 on one GPU, row-major item pass, algorithmic bytes / time)")
         (ROOT / "profiles" / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
     c3 = src / "bench_c3_full_1gpu.json"
     if c3.exists() and c3.read_text().strip():
