@@ -192,6 +192,17 @@ namespace {
 // per iteration, instead of as a hang in a later collective
 int check_comm_async(hpf_handle *h);
 
+// inside a do { ... } while (0) body that ends in the function's clean-up: sets rc and leaves the body
+#define HIPBRK(h, expr)                                                        \
+  {                                                                            \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);            \
+      rc = (e_ == hipErrorOutOfMemory) ? HPF_ERR_OOM : HPF_ERR_HIP;            \
+      break;                                                                   \
+    }                                                                          \
+  }
+
 #define HIPCHK(h, expr)                                                        \
   do {                                                                         \
     hipError_t e_ = (expr);                                                    \
@@ -800,19 +811,19 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     if ((rc = check_launch(h, "seg_count_kernel"))) break;
     if ((rc = device_scan<uint64_t>(h, cnt, nwt, cnt, true))) break;
     uint64_t nseg64 = 0;
-    HIPCHK(h, hipMemcpyAsync(&nseg64, cnt + nwt, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPBRK(h, hipMemcpyAsync(&nseg64, cnt + nwt, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPBRK(h, hipStreamSynchronize(h->stream));
     if (nseg64 == 0 || nseg64 > 0x7fffffffull) break;              // leaves the plain list in place
     const uint32_t nseg = (uint32_t)nseg64;
     if ((rc = dalloc(h, &segs, nseg)) || (rc = dalloc(h, &seg_row, nseg)) || (rc = dalloc(h, &seg_key, nseg)) ||
         (rc = dalloc(h, &first_seg, nkeys))) break;
-    HIPCHK(h, hipMemsetAsync(first_seg, 0xff, (size_t)nkeys * 4, h->stream));
+    HIPBRK(h, hipMemsetAsync(first_seg, 0xff, (size_t)nkeys * 4, h->stream));
     hipLaunchKernelGGL(seg_emit_kernel, dim3(wblk), dim3(256), 0, h->stream, skey, srow, nnz, h->seg_max, cnt, segs, seg_row, seg_key);
     hipLaunchKernelGGL(seg_len_kernel, dim3(grid_for(nseg)), dim3(256), 0, h->stream, segs, nseg, nnz, seg_key, first_seg);
     if ((rc = check_launch(h, "seg_emit_kernel"))) break;
     std::vector<uint32_t> fs(nkeys);
-    HIPCHK(h, hipMemcpyAsync(fs.data(), first_seg, (size_t)nkeys * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPBRK(h, hipMemcpyAsync(fs.data(), first_seg, (size_t)nkeys * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPBRK(h, hipStreamSynchronize(h->stream));
     dfree(b.K[r]); dfree(b.U[r]); b.K[r] = b.U[r] = nullptr;
     dfree(cnt); cnt = nullptr; dfree(seg_key); seg_key = nullptr; dfree(first_seg); first_seg = nullptr;
 
@@ -834,8 +845,12 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     for (int k = 0; k < 5 && !rc; ++k) rc = device_scan<uint64_t>(h, pl[k], s.rows, pl[k], true);
     if (rc) break;
     uint64_t tot[5];
-    for (int k = 0; k < 5; ++k) HIPCHK(h, hipMemcpyAsync(&tot[k], pl[k] + s.rows, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+      hipError_t e = hipSuccess;
+      for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipMemcpyAsync(&tot[k], pl[k] + s.rows, 8, hipMemcpyDeviceToHost, h->stream);
+      HIPBRK(h, e);
+    }
+    HIPBRK(h, hipStreamSynchronize(h->stream));
     if (tot[1] > 0x7fffffffull) break;
     const uint32_t npartial = (uint32_t)tot[1], nlong = (uint32_t)tot[2], nhuge = (uint32_t)tot[3], ngroup = (uint32_t)tot[4];
     if ((rc = dalloc(h, &longs, nlong))) break;
@@ -902,8 +917,8 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     std::vector<uint2> chunks(longest * 8, make_uint2(0u, 0u));
     for (int x = 0; x < 8; ++x) for (size_t j = 0; j < qc[x].size(); ++j) chunks[j * 8 + x] = qc[x][j];
     if ((rc = dalloc(h, &chunks_dev, chunks.size()))) break;
-    HIPCHK(h, hipMemcpyAsync(chunks_dev, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPBRK(h, hipMemcpyAsync(chunks_dev, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    HIPBRK(h, hipStreamSynchronize(h->stream));
 
     // ---- swap the side's work list
     dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows); dfree(s.partial); dfree(s.partial2);
@@ -919,12 +934,16 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     (void)tiled_segs;
     done = true;
   } while (0);
-  (void)done;
   dfree(tilemap); dfree(first_seg); dfree(seg_row); dfree(seg_key); dfree(iota); dfree(cnt); dfree(segptr);
   for (int k = 0; k < 5; ++k) dfree(pl[k]);
   for (int k = 0; k < 2; ++k) { dfree(b.K[k]); dfree(b.U[k]); dfree(b.X[k]); dfree(b.V[k]); dfree(sb.K[k]); dfree(sb.U[k]); }
   dfree(key0); dfree(row0); dfree(segs); dfree(longs); dfree(huges); dfree(groups); dfree(partial); dfree(partial2);
   dfree(chunks_dev); dfree(keep_idx); dfree(keep_val);
+  if (rc == HPF_ERR_OOM && !done) {       // tiling is optional: without the room for it the side stays row-major
+    (void)hipGetLastError();
+    h->err.clear();
+    rc = HPF_OK;
+  }
   return rc;
 }
 

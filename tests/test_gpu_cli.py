@@ -58,6 +58,7 @@ def series(p):
     (["-hier", "-novb"], 5, 8),    # vb_hier() never reads the flag; only the directory name changes
     (["-hier"], 100, 6),               # K = 100: rows of W packed at 59 bits (the library's default there)
     (["-hier", "-plain-rows"], 100, 4),  # ... and kept plain (extension flag, hpf_config.w_storage = 3)
+    (["-hier", "-no-tiles"], 100, 4),    # extension flag, hpf_config.tiling = 1 (this matrix is row-major either way)
     (["-hier", "-bias", "-logl"], 6, 8),
     (["-logl"], 4, None),
     (["-hier", "-rfreq", "50"], 5, 100),      # iteration 100: ranking.tsv + itemrank.tsv + meanrank.txt
