@@ -905,15 +905,26 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
       for (auto &rg : qt[x]) q[x].push_back(rg);
       if (!front && hi > lo) q[x].push_back({lo, hi});
     }
-    const uint32_t CH = std::max<uint32_t>(h->tile_chunk, 1);
+    // a launch holds fewer than 2^32 work-items (the AQL packet counts them in 32 bits): at most 2^20 workgroups,
+    // so a list too long for chunks of tile_chunk segments gets longer chunks
+    uint32_t CH = std::max<uint32_t>(h->tile_chunk, 1);
+    for (;; CH *= 2) {
+      size_t worst = 0;
+      for (int x = 0; x < 8; ++x) {
+        size_t c = 0;
+        for (auto &rg : q[x]) c += (rg.second - rg.first + CH - 1) / CH;
+        worst = std::max(worst, c);
+      }
+      if (worst * 8 <= (1u << 20) || CH >= (1u << 30)) break;
+    }
     std::vector<uint2> qc[8];
     size_t longest = 0;
     for (int x = 0; x < 8; ++x) {
       for (auto &rg : q[x])
-        for (uint32_t c0 = rg.first; c0 < rg.second; c0 += CH) qc[x].push_back(make_uint2(c0, std::min(c0 + CH, rg.second)));
+        for (uint32_t c0 = rg.first; c0 < rg.second; c0 += std::min(CH, rg.second - c0)) qc[x].push_back(make_uint2(c0, c0 + std::min(CH, rg.second - c0)));
       longest = std::max(longest, qc[x].size());
     }
-    if (longest == 0 || longest * 8 > 0x7fffffffull) break;
+    if (longest == 0 || longest * 8 > (1u << 20)) break;
     std::vector<uint2> chunks(longest * 8, make_uint2(0u, 0u));
     for (int x = 0; x < 8; ++x) for (size_t j = 0; j < qc[x].size(); ++j) chunks[j * 8 + x] = qc[x][j];
     if ((rc = dalloc(h, &chunks_dev, chunks.size()))) break;

@@ -177,3 +177,27 @@ def test_automatic_policy_tiles_a_skewed_side_only(orc):
     ms = D.gather_only_ms(1, 2)                      # the probe walks the same chunks
     assert ms > 0
     D.close()
+
+
+def test_tiled_list_longer_than_a_launch_holds(tile_env):
+    """A launch holds fewer than 2^32 work-items, i.e. 2^20 workgroups of 256: with 1 KiB tiles this
+    matrix is cut into ~10^7 segments -- more than 2^20 chunks of eight -- so the chunks must grow
+    instead of the grid.  (A grid past the limit is silently cut short: found with whole-suite runs
+    under forced tiling.)  The phi sums of a row add up to its ratings whatever the state is."""
+    import torch
+    from tests.test_gpu_fullsize import _device_model, _row_mass
+    from hgaprec_amd import synth
+    tile_env(HPF_TILE=1, HPF_TILE_BYTES=1024)
+    n, m, nnz, K = 200_000, 20_000, 20_000_000, 5
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate_device(n, m, nnz, 0.4, 0.7, seed=5, device=dev, binary=True)
+    D = _device_model(dict(m=m, K=K, binary=True), n, rowptr, col, None, 0, n)
+    wi = D.work_info()
+    assert wi["tiles_user"] > 100 and wi["tiles_item"] > 1000 and wi["item_segments"] > 8 * (1 << 20), wi
+    D.iterate(2)
+    ts, bs = D.get_state_device("THETA_SHAPE", dev), D.get_state_device("BETA_SHAPE", dev)
+    deg_u = _row_mass(rowptr, None)
+    assert float((((ts - 0.3).sum(1) - deg_u).abs() / deg_u.clamp(min=1.0)).max()) < 1e-11
+    deg_i = torch.bincount(col.to(torch.int64), minlength=m).to(torch.float64)
+    assert float((((bs - 0.3).sum(1) - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
+    D.close()
