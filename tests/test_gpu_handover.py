@@ -178,7 +178,11 @@ def test_stray_tuning_variables_are_ignored(monkeypatch):
     monkeypatch.setenv("HPF_HUGE_SLOTS", "8")
     monkeypatch.setenv("HPF_PHI_CFG", "16,1,2")
     monkeypatch.setenv("HPF_GRAPH", "0")
-    assert info() == base
+    monkeypatch.setenv("HPF_TILE", "1")
+    monkeypatch.setenv("HPF_TILE_BYTES", "4096")
+    monkeypatch.delenv("HPF_EXPERIMENTAL", raising=False)
+    assert info() == base and base["tiles_user"] == 0 and base["tiles_item"] == 0
     monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     w = info()
     assert w["user_segments"] > base["user_segments"] and w["ld"] == 32 and w["graph_replay"] == 0
+    assert w["tiles_user"] > 1 and w["tiles_item"] > 1
