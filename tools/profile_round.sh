@@ -29,6 +29,7 @@ done
 # off, and the L2 hit rate of the item pass either way; l2probe = a pass whose gathered rows fit one L2
 tools/xcc_probe 200000 2000 > $OUT/xcc_probe.json 2> $OUT/xcc_probe.log
 tools/xcc_probe 50000 20000 >> $OUT/xcc_probe.json 2>> $OUT/xcc_probe.log
+tools/xcd_fabric_probe > $OUT/xcd_fabric_probe.json 2> $OUT/xcd_fabric_probe.log
 HPF_EXPERIMENTAL=1 HPF_TILE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_untiled.json 2> $OUT/bench_c2_untiled.log
 HPF_EXPERIMENTAL=1 HPF_TILE=0 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc_untiled -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_tcc_untiled.log
 HPF_EXPERIMENTAL=1 HPF_TILE=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_untiled -o c2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch_untiled.log
