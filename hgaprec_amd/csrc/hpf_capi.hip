@@ -122,7 +122,7 @@ struct hpf_handle {
   // 4.39 ms; 0 = in front everywhere 4.75; 2 = dealt between the tiles 4.58)
   int tile_order = 1;
   int tile_sides = 3;                   // HPF_TILE_SIDES: bit 0 the user pass, bit 1 the item pass (experiments)
-  int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 8, tile_min_run = 16; double tile_min_share = 0.15;
+  int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 8, tile_min_run = 0; double tile_min_share = 0.15;
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
@@ -750,7 +750,11 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   // a gathered matrix of a few tiles is already served largely from L2 when the ratings are skewed (the popular
   // rows stay resident): regrouping then pays only for rows that meet a tile many times (size sweep, m = 20 000:
   // four tiles, user pass 3.19 ms row-major, 3.64 ms with runs of 16)
-  uint64_t light_below = (uint64_t)tiles * h->tile_min_run * (tiles < 8 ? 4u : 1u);
+  // ... and a run is worth its fixed work from two batches on: a batch is 64 / G nonzeros (K = 50: G = 4, sixteen
+  // per batch -- with runs of 16 its ten-tile user side went 2.31 -> 2.68 ms)
+  const uint32_t min_run = h->tile_min_run ? h->tile_min_run                    // HPF_TILE_RUN: as given
+                                           : std::max<uint32_t>(16u, h->phiG > 0 ? 2u * (64u / (uint32_t)h->phiG) : 0u);
+  uint64_t light_below = (uint64_t)tiles * min_run * (tiles < 8 ? 4u : 1u);
   if (h->tile_mode == 1) light_below = 0;                         // forced: every row is regrouped
   unsigned long long *stat = nullptr;
   uint64_t heavy_rows = 0, heavy_nnz = nnz;
@@ -908,11 +912,26 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     // a launch holds fewer than 2^32 work-items (the AQL packet counts them in 32 bits): at most 2^20 workgroups,
     // so a list too long for chunks of tile_chunk segments gets longer chunks
     uint32_t CH = std::max<uint32_t>(h->tile_chunk, 1);
-    for (;; CH *= 2) {
+    // the row-major segments of a side with short rows (users: a few batches each) come in chunks of ~4096 nonzeros:
+    // a workgroup that lives for two 40-nonzero rows costs more to dispatch than to run (K = 50, 10^6 light users
+    // in chunks of 8: user pass 2.27 -> 2.54 ms)
+    uint32_t CHc = CH;
+    if (c1 > c0) {
+      int64_t cold_nnz = (int64_t)nnz;
+      if (c1 < nseg) {
+        Seg first_tiled;
+        HIPBRK(h, hipMemcpy(&first_tiled, segs + c1, sizeof(Seg), hipMemcpyDeviceToHost));
+        cold_nnz = first_tiled.start;
+      }
+      const uint64_t avg = std::max<uint64_t>((uint64_t)cold_nnz / (c1 - c0), 1);
+      CHc = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096 / avg, CH), 512);
+    }
+    auto chunk_of = [&](const std::pair<uint32_t, uint32_t> &rg, uint32_t ch, uint32_t chc) { return (rg.first >= c0 && rg.second <= c1) ? chc : ch; };
+    for (;; CH *= 2, CHc *= 2) {
       size_t worst = 0;
       for (int x = 0; x < 8; ++x) {
         size_t c = 0;
-        for (auto &rg : q[x]) c += (rg.second - rg.first + CH - 1) / CH;
+        for (auto &rg : q[x]) { const uint32_t ch = chunk_of(rg, CH, CHc); c += (rg.second - rg.first + ch - 1) / ch; }
         worst = std::max(worst, c);
       }
       if (worst * 8 <= (1u << 20) || CH >= (1u << 30)) break;
@@ -920,8 +939,10 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     std::vector<uint2> qc[8];
     size_t longest = 0;
     for (int x = 0; x < 8; ++x) {
-      for (auto &rg : q[x])
-        for (uint32_t c0 = rg.first; c0 < rg.second; c0 += std::min(CH, rg.second - c0)) qc[x].push_back(make_uint2(c0, c0 + std::min(CH, rg.second - c0)));
+      for (auto &rg : q[x]) {
+        const uint32_t ch = chunk_of(rg, CH, CHc);
+        for (uint32_t p0 = rg.first; p0 < rg.second; p0 += std::min(ch, rg.second - p0)) qc[x].push_back(make_uint2(p0, p0 + std::min(ch, rg.second - p0)));
+      }
       longest = std::max(longest, qc[x].size());
     }
     if (longest == 0 || longest * 8 > (1u << 20)) break;
