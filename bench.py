@@ -569,6 +569,9 @@ def main():
                 # the gathered matrix and a tile's segments run on one XCD, out of its L2.  `achieved` stays
                 # ALGORITHMIC bytes / time (every gathered row counted once per nonzero), so with tiling it can
                 # pass the HBM peak: the tiled share of those bytes never crosses the fabric -- `traffic` shows it
+                "frac_note": ("frac > 1: `achieved` counts every gathered row once per nonzero (the contract's algorithmic "
+                              "bytes); the tiled share of those rows is served by the XCDs' L2s, so fewer bytes than that "
+                              "cross the fabric -- see `traffic` and `fabric_side_GBps`") if achieved > HBM_PEAK_GBS else None,
                 "tiles": {"phi_item": wi["tiles_item"], "phi_user": wi["tiles_user"],
                           "note": "0 = row-major pass; >0 = heavy rows regrouped by that many tiles of the gathered rows"},
                 "hbm_copy_measured_GBps": copy_gbs,
