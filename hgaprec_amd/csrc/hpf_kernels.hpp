@@ -321,12 +321,17 @@ template <int L> struct codec_p59 {
   {
     const int o = 27 * e, i = E + o / 32, sh = o % 32;    // compile-time after unrolling
     uint32_t f;
-    if (sh + 27 <= 32) f = (d[i] >> sh) & 0x7ffffffu;     // v_bfe_u32
-    else f = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) & 0x7ffffffu;
+    if (sh == 0) f = d[i];
+    else if (sh + 27 <= 32) f = d[i] >> sh;
+    else f = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
     // exponent field + 896.  The all-zero element (padding columns, a flushed entry) decodes to
-    // 2^-127 = 5.9e-39 instead of 0 -- one add instead of a compare and two selects per element:
-    // products of two such entries are 3e-77, below any sum they could join by sixty orders
-    return __hiloint2double((int)(f + 0x38000000u), (int)d[e]);
+    // 2^-127 = 5.9e-39 instead of 0 -- no compare and two selects per element: products of two such
+    // entries are 3e-77, below any sum they could join by sixty orders.  Mask and bias in ONE
+    // instruction: v_and_or_b32 takes no literal on gfx9, so the mask sits in an SGPR and the bias in
+    // a VGPR (the compiler left to itself emits v_and + v_or with literals)
+    uint32_t hi;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(f), "s"(0x7ffffffu), "v"(0x38000000u));
+    return __hiloint2double((int)hi, (int)d[e]);
   }
 };
 

@@ -297,7 +297,10 @@ int  hpf_item_ranks(hpf_handle *h, const uint32_t *users, uint32_t n_sel,
 /* how the uploaded matrix was cut into work (diagnostics, tests, bench):
  * a "segment" is <= 512 consecutive nonzeros of one row; rows longer than that
  * are "long" (their segment sums are combined by a second kernel) and rows with
- * more than 256 segments "huge" (combined in two levels). */
+ * more than 256 segments "huge" (combined in two levels).  On a TILED side
+ * (tiles_* > 0) a segment is a run of one row inside one tile of the gathered
+ * matrix, and the long rows also count the rows without any nonzero (the
+ * combine zeroes them). */
 typedef struct {
   uint64_t nnz;
   uint32_t user_segments, user_long_rows, user_huge_rows;
