@@ -27,6 +27,10 @@ for v in base xcd; do
 done
 # 4b. the tiled pass: where workgroups run, the same bench line with the tiles switched
 # off, and the L2 hit rate of the item pass either way; l2probe = a pass whose gathered rows fit one L2
+if [ -x /opt/rocm/bin/hipcc ]; then
+  [ -x tools/xcc_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/xcc_probe tools/xcc_probe.hip > /dev/null 2>&1
+  [ -x tools/xcd_fabric_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/xcd_fabric_probe tools/xcd_fabric_probe.hip > /dev/null 2>&1
+fi
 tools/xcc_probe 200000 2000 > $OUT/xcc_probe.json 2> $OUT/xcc_probe.log
 tools/xcc_probe 50000 20000 >> $OUT/xcc_probe.json 2>> $OUT/xcc_probe.log
 tools/xcd_fabric_probe > $OUT/xcd_fabric_probe.json 2> $OUT/xcd_fabric_probe.log
