@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int64_t *ptr, uint3
 // order, and every gathered row crosses the fabric once per pass instead of once per nonzero.
 // The nonzeros of the light rows keep key 0: they stay row-major and are gathered as before.
 //
-//   tile_map_kernel       gathered row -> tile id (1 + row / T), or 1 / 0 for a "hot set" by degree
+//   tile_map_kernel       gathered row -> tile id (1 + row / T; a table, so that another grouping is one kernel away)
 //   tile_key_kernel       nonzero -> sort key: 0 for a light owner row, else the tile of its gathered row
 //   (radix sort on the key, stable: inside a key the order stays owner row, then as uploaded)
 //   seg_count / seg_emit  segments = maximal runs of one (key, owner row), cut at multiples of seg_max
@@ -344,11 +344,10 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const int64_t *ptr, uint3
 //                         the combine), plus the LongRow lists of the combine kernels
 // All integer work, deterministic: no atomics decide an order.
 // ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_map_kernel(uint32_t *tilemap, uint32_t rows, uint32_t T,
-                                                       const int64_t *ptr, uint64_t hot_cutoff)
+__global__ __launch_bounds__(256) void tile_map_kernel(uint32_t *tilemap, uint32_t rows, uint32_t T)
 {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
-    tilemap[r] = hot_cutoff ? ((uint64_t)(ptr[r + 1] - ptr[r]) >= hot_cutoff ? 1u : 0u) : 1u + r / T;
+    tilemap[r] = 1u + r / T;
 }
 
 // sum of the degrees >= cutoff and how many rows have one (two integers: order-free)

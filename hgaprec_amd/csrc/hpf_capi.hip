@@ -789,8 +789,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   do {
     // ---- keys and the sort
     if ((rc = dalloc(h, &tilemap, rows_oth)) || (rc = dalloc(h, &key0, (size_t)nnz)) || (rc = dalloc(h, &row0, (size_t)nnz))) break;
-    hipLaunchKernelGGL(tile_map_kernel, dim3(grid_for(rows_oth)), dim3(256), 0, h->stream, tilemap, rows_oth, T,
-                       (const int64_t *)nullptr, (uint64_t)0);
+    hipLaunchKernelGGL(tile_map_kernel, dim3(grid_for(rows_oth)), dim3(256), 0, h->stream, tilemap, rows_oth, T);
     const uint64_t nwt = (nnz + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t wblk = (uint32_t)((nwt + 3) / 4);
     hipLaunchKernelGGL(tile_key_kernel, dim3(wblk), dim3(256), 0, h->stream, ptr, s.rows, s.idx, nnz, tilemap, light_below,
