@@ -150,6 +150,13 @@ struct Driver {
     for (auto &v : rp) v -= base;
     rc = hpf_upload_csr(h, rp.data(), rt.col.data() + base, env.binary_data ? nullptr : rt.val.data() + base);
     if (rc) die("hpf_upload_csr", rc);
+    {
+      hpf_work_info wi;
+      if (root() && hpf_get_work_info(h, &wi) == HPF_OK)      // infer.log: how the device side laid the work out
+        env.lerr("device: rows of W %s, %u columns; phi passes: user %s (%u tiles), item %s (%u tiles)",
+                 wi.w_layout == 3 ? "packed 59-bit (lossless)" : wi.w_layout == 2 ? "48-bit (opt-in)" : "plain fp64", wi.ld,
+                 wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.tiles_item ? "tiled" : "row-major", wi.tiles_item);
+    }
 
     if (comm.world > 1 && use_rccl) {                      // bootstrap the RCCL communicator
       char id[HPF_COMM_ID_BYTES]; memset(id, 0, sizeof id);
