@@ -86,6 +86,72 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
     }
 
 
+def pmc_passes(argv_workload, n_rows_big, ld, tmo=600):
+    """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
+    passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
+    slots") over `bench.py --lean --steps 3 --warmup 1` of the same workload, spawned after the
+    timed region while this process is idle.  Per launch: bytes = 2 x FETCH_SIZE x 1024 / cal +
+    WRITE_SIZE x 1024, the x 2 being the guide's gfx950 correction and `cal` its calibration in the
+    same pass on materialize_es_kernel, which reads n_rows_big x ld doubles by construction.
+    -> ({side: {"fetch_KiB", "write_KiB", "launches"}}, cal dict, note) or (None, None, why)"""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="hpf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HPF_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    per = {0: {}, 1: {}}
+    cal = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr.lower())
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, str(ROOT / "bench.py"), "--lean", "--steps", "3", "--warmup", "1"] + argv_workload
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=tmo)
+            if r.returncode != 0:
+                return None, None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            vals = {0: [], 1: []}
+            calv = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    name = row["Kernel_Name"]
+                    if "phi_pass" in name:
+                        mt = re.search(r",\s*(\d)>\(", name)
+                        if mt:
+                            vals[int(mt.group(1))].append(float(row["Counter_Value"]))
+                    elif "materialize_es_kernel" in name:
+                        calv.append(float(row["Counter_Value"]))
+            for sd in (0, 1):
+                v = vals[sd][1:] if len(vals[sd]) > 1 else vals[sd]        # the first launch is the warm-up iteration
+                if v:
+                    per[sd][ctr] = sum(v) / len(v)
+                    per[sd]["launches"] = len(v)
+            if calv:
+                cal[ctr] = max(calv) * 1024.0                                # the larger side's launch
+        if not all("FETCH_SIZE" in per[sd] and "WRITE_SIZE" in per[sd] for sd in (0, 1)):
+            return None, None, "rocprofv3 ran but the phi kernels were not in its counter CSV"
+        known_read = float(n_rows_big) * ld * 8
+        c = {"fetch_x2_over_known_read": 2.0 * cal["FETCH_SIZE"] / known_read if cal.get("FETCH_SIZE") else None,
+             "write_over_known_write": cal["WRITE_SIZE"] / (2.0 * known_read) if cal.get("WRITE_SIZE") else None,
+             "kernel": "materialize_es_kernel: reads rows x ld doubles, writes twice that, by construction",
+             "seconds": round(time.perf_counter() - t0, 1)}
+        return per, c, "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over bench.py --lean --steps 3 --warmup 1"
+    except Exception as ex:
+        return None, None, f"in-run PMC passes failed: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def kernels_sha():
     h = hashlib.sha256()
     for f in ("hpf_kernels.hpp", "hpf_build.hpp"):    # the kernels and the work lists they walk: what the traffic was measured on
@@ -109,6 +175,127 @@ def measured_traffic(config, kern):
     return d.get(f"{config}:{kern}"), f"PMC passes of {d.get('measured', '?')}"
 
 
+def start_state(H, cfg, rows, first_row, seed_users, n_total, dev):
+    """bench-mode initial state (counter hash; the parity path uses MT19937), a function of the
+    GLOBAL row: shards of one problem start from one state"""
+    import torch
+    from hgaprec_amd import synth
+    m, K = cfg["m"], cfg["K"]
+
+    def put(names, st):
+        for w, k in names:
+            H.set_state_device(w, st[k])
+    put((("THETA_SHAPE", "shape"), ("THETA_E", "E"), ("THETA_ELOG", "Elog")),
+        synth.initial_state_device(rows, K, seed_users + 17, dev, row0=first_row))
+    put((("BETA_SHAPE", "shape"), ("BETA_E", "E"), ("BETA_ELOG", "Elog")),
+        synth.initial_state_device(m, K, cfg["seed"] + 29, dev))
+    if cfg["hier"]:
+        put((("XI_E", "E"),), synth.initial_state_device(rows, K, seed_users + 31, dev, prior_v=K, row0=first_row))
+        put((("ETA_E", "E"),), synth.initial_state_device(m, K, cfg["seed"] + 37, dev, prior_v=K))
+    if cfg["bias"]:
+        put((("UBIAS_E", "E"), ("UBIAS_ELOG", "Elog"), ("UBIAS_SHAPE", "shape")),
+            synth.initial_state_device(rows, K, seed_users + 41, dev, prior_v=m, row0=first_row))
+        put((("IBIAS_E", "E"), ("IBIAS_ELOG", "Elog"), ("IBIAS_SHAPE", "shape")),
+            synth.initial_state_device(m, K, cfg["seed"] + 43, dev, prior_v=n_total))
+    torch.cuda.empty_cache()
+
+
+def mass_check(D, cfg, nnz_loc, val, dev):
+    """every nonzero's phi sums to max(y, 1): the shape rows of this handle's users must hold exactly
+    that mass (+ priors).  Blind to WHICH rows were gathered -- that is what sampled_rows is for."""
+    import torch
+    ts = D.get_state_device("THETA_SHAPE", dev)
+    got = float((ts - 0.3).sum())
+    del ts
+    if cfg["bias"]:
+        got += float((D.get_state_device("UBIAS_SHAPE", dev) - 0.3).sum())
+    want_k = float(nnz_loc) if val is None else float(torch.clamp(val, min=1).to(torch.float64).sum())
+    if cfg["bias"]:
+        # the item-bias slot's share went to the items: bound instead of equality
+        return {"user_side_mass_fraction": got / want_k, "ok": bool(0.0 < got <= want_k * (1 + 1e-9))}
+    return {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
+
+
+def sampled_rows(D, cfg, rowptr, col, val, n_users, n_items):
+    """value check of the handle just timed: ONE more iteration, the phi sums of a sample of owner
+    rows recomputed in plain fp64 from the exported Elog arrays (tests/rowcheck.py; outside `value`)"""
+    try:
+        from tests import rowcheck
+        r = rowcheck.check_handle(D, rowptr, col, val, bias=cfg["bias"], n_users=n_users, n_items=n_items, seed=7)
+        r["what"] = ("one more iteration; raw phi sums of the sampled user and item rows (random, last, heaviest, rows cut "
+                     "into several segments, rows at the heavy/light bar and at tile boundaries) recomputed in fp64 from "
+                     "the exported Elog arrays vs shape - 0.3 from the device, max relative error; bar 1e-9")
+        return r
+    except Exception as ex:
+        return {"error": str(ex), "ok": False}
+
+
+def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2):
+    """one of the OTHER BASELINE shapes on this GPU, outside `value`: generate, hand over, time a few
+    iterations with the library's hipEvents, mass + sampled-row checks.  -> dict"""
+    import torch
+    from hgaprec_amd import synth
+    from hgaprec_amd.capi import Hpf
+    cfg = dict(synth.CONFIGS[name])
+    cfg.update(over)
+    n, m, K = cfg["n"], cfg["m"], cfg["K"]
+    t0 = time.perf_counter()
+    try:
+        need = (n + m) * (K + 8) * 8 * 5 + cfg["nnz"] * 40          # state + CSR/CSC/tiled copies + the sort's temporaries
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        if need > 0.8 * free_b:
+            return {"skipped": f"needs ~{need / 1e9:.0f} GB, {free_b / 1e9:.0f} GB free"}
+        rowptr, col, val = synth.generate_device(n, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"],
+                                                 device=dev, binary=cfg["binary"])
+        nnz = int(rowptr[-1])
+        torch.cuda.empty_cache()
+        D = Hpf(n, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
+                stream=stream.cuda_stream, n_users_total=over.get("n_users_total", n))
+        D.upload_csr_device(rowptr, col, val)
+        start_state(D, cfg, n, 0, cfg["seed"], over.get("n_users_total", n), dev)
+        D.iterate(warmup)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        D.iterate(steps)
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t1) / steps * 1e3
+        tm = D.mean_timing(steps)
+        its = D.iteration_times(steps)
+        wi = D.work_info()
+        ab = D.algorithmic_bytes()
+        out = {
+            "workload": f"{n} users x {m} items, {nnz} nonzeros, K={K}" + (", -bias" if cfg["bias"] else "")
+                        + (", -binary-data" if cfg["binary"] else "") + over.get("_what", ""),
+            "value": nnz / (wall_ms * 1e-3), "ms_per_step": wall_ms,
+            "ms_per_step_median_hipevent": float(np.median(its)) if its.size else None,
+            "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+            "tiles": {"user": wi["tiles_user"], "item": wi["tiles_item"]}, "w_layout": wi["w_layout"],
+            "algorithmic_bytes": ab,
+            "self_check": mass_check(D, cfg, nnz, val, dev),
+        }
+        out["self_check"]["sampled_rows"] = sampled_rows(D, cfg, rowptr, col, val, 24, 8)
+        out["self_check"]["ok"] = bool(out["self_check"]["ok"] and out["self_check"]["sampled_rows"].get("ok"))
+        D.close()
+        del rowptr, col, val
+        torch.cuda.empty_cache()
+        out["seconds"] = round(time.perf_counter() - t0, 1)
+        return out
+    except Exception as ex:
+        torch.cuda.empty_cache()
+        return {"error": str(ex), "seconds": round(time.perf_counter() - t0, 1)}
+
+
+# what 8 GPUs hold of C3 and C5 (the size of one nnz-balanced shard, all items), and C4 whole: every
+# BASELINE shape gets a number timed in the driver's own run (never part of `value`)
+OTHER_CONFIGS = (
+    ("C4", "C4", {}),
+    ("C3_shard_of_8", "C3", {"n": 1_250_000, "nnz": 125_000_000, "n_users_total": 10_000_000,
+                             "_what": " (what one of 8 GPUs holds of C3: 1/8 of the users, all items)"}),
+    ("C5_shard_of_8", "C5", {"n": 6_250_000, "nnz": 625_000_000, "n_users_total": 50_000_000,
+                             "_what": " (the size of what one of 8 GPUs holds of C5: 1/8 of the users, all items)"}),
+)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +306,11 @@ def main():
                     help="N > 1: weak scaling -- every rank owns its own C2-sized user shard")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n, m, nnz (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="the timed region and the mass check only: no gather-only probe, copy rate, 48-bit block, "
+                         "other configs, PMC passes or CPU baseline (what the in-run rocprofv3 passes execute)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the in-run rocprofv3 --pmc passes")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C3-shard / C5-shard blocks")
     ap.add_argument("--n", type=int, default=0, help="override users (experiments)")
     ap.add_argument("--m", type=int, default=0, help="override items (experiments)")
     ap.add_argument("--nnz", type=int, default=0, help="override nonzeros (experiments)")
@@ -141,6 +333,8 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="debug: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
+    if args.lean:
+        args.no_pmc = args.no_other_configs = args.no_cpu_baseline = True
 
     # RCCL prints a version banner through C stdio on stdout (flushed at process
     # exit when stdout is a pipe).  Keep the real stdout for the ONE JSON line:
@@ -272,30 +466,9 @@ def main():
     D.synchronize()
     t_upload = time.perf_counter() - t0
 
-    # ---- bench-mode initial state (counter hash; the parity path uses MT19937),
-    # a function of the GLOBAL row: shards of one problem start from one state
     t0 = time.perf_counter()
     ss = cfg["seed"] + state_seed_shift
-
-    def start_state(H, rows, first_row, seed_users):
-        def put(names, st):
-            for w, k in names:
-                H.set_state_device(w, st[k])
-        put((("THETA_SHAPE", "shape"), ("THETA_E", "E"), ("THETA_ELOG", "Elog")),
-            synth.initial_state_device(rows, K, seed_users + 17, dev, row0=first_row))
-        put((("BETA_SHAPE", "shape"), ("BETA_E", "E"), ("BETA_ELOG", "Elog")),
-            synth.initial_state_device(m, K, cfg["seed"] + 29, dev))
-        if cfg["hier"]:
-            put((("XI_E", "E"),), synth.initial_state_device(rows, K, seed_users + 31, dev, prior_v=K, row0=first_row))
-            put((("ETA_E", "E"),), synth.initial_state_device(m, K, cfg["seed"] + 37, dev, prior_v=K))
-        if cfg["bias"]:
-            put((("UBIAS_E", "E"), ("UBIAS_ELOG", "Elog"), ("UBIAS_SHAPE", "shape")),
-                synth.initial_state_device(rows, K, seed_users + 41, dev, prior_v=m, row0=first_row))
-            put((("IBIAS_E", "E"), ("IBIAS_ELOG", "Elog"), ("IBIAS_SHAPE", "shape")),
-                synth.initial_state_device(m, K, cfg["seed"] + 43, dev, prior_v=n_total))
-        torch.cuda.empty_cache()
-
-    start_state(D, n_loc, row0, ss)
+    start_state(D, cfg, n_loc, row0, ss, n_total, dev)
     t_state = time.perf_counter() - t0
     log(f"[rank {rank}] device hand-over: csr {t_upload:.2f}s, state {t_state:.2f}s")
 
@@ -333,6 +506,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tm = D.mean_timing(min(args.steps, 64))
+    it_ms = D.iteration_times(min(args.steps, 64))          # hipEvents on the handle's stream, one figure per timed iteration
     per_rank = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -407,28 +581,23 @@ def main():
             except Exception as ex:
                 rccl["log"] = {"error": str(ex)}
 
-    # the timed iterations did the work: every nonzero's phi sums to max(y, 1), so
-    # the shape rows of this rank's users must hold exactly that mass (+ priors)
-    ts = D.get_state_device("THETA_SHAPE", dev)
-    got = float((ts - 0.3).sum())
-    del ts
-    if cfg["bias"]:
-        got += float((D.get_state_device("UBIAS_SHAPE", dev) - 0.3).sum())
-    want_k = float(nnz_loc) if val is None else float(torch.clamp(val, min=1).to(torch.float64).sum())
-    if cfg["bias"]:
-        # the item-bias slot's share went to the items: bound instead of equality
-        self_check = {"user_side_mass_fraction": got / want_k, "ok": bool(0.0 < got <= want_k * (1 + 1e-9))}
-    else:
-        self_check = {"mass_rel_err": abs(got - want_k) / want_k, "ok": bool(abs(got - want_k) / want_k < 1e-9)}
+    # the timed iterations did the work: mass conservation on the handle that was timed ...
+    self_check = mass_check(D, cfg, nnz_loc, val, dev)
     ab = D.algorithmic_bytes()
     wi = D.work_info()
     # the ceiling of each phi pass's ACCESS PATTERN on this GPU, measured now: the same work list,
     # index stream and rows with the arithmetic taken out (hpf_gather_only).  Outside the timed region.
     gather_only = None
-    try:
-        gather_only = {"phi_user": D.gather_only_ms(0, 3), "phi_item": D.gather_only_ms(1, 3)}
-    except Exception as ex:
-        gather_only = {"error": str(ex)}
+    if not args.lean:
+        try:
+            gather_only = {"phi_user": D.gather_only_ms(0, 3), "phi_item": D.gather_only_ms(1, 3)}
+        except Exception as ex:
+            gather_only = {"error": str(ex)}
+    # ... and the VALUES of a sample of its rows (one more iteration, outside the timed region): a gather of
+    # the wrong row conserves mass; this does not pass it
+    if world == 1 and not force_dist and not args.lean:
+        self_check["sampled_rows"] = sampled_rows(D, cfg, rowptr, col, val, 48, 16)
+        self_check["ok"] = bool(self_check["ok"] and self_check["sampled_rows"].get("ok"))
 
     handover = {"generate_s": round(t_gen, 3), "upload_csr_device_s": round(t_upload, 3),
                 "set_state_device_s": round(t_state, 3)}
@@ -455,7 +624,7 @@ def main():
         del rp_h, col_h, val_h, a
 
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and not args.lean:
         # context for the roofline: what a plain device-to-device copy reaches on
         # this GPU right now (read + write bytes / time), outside the timed region
         src = torch.empty(1 << 27, dtype=torch.float64, device=dev)        # 1 GiB
@@ -470,53 +639,9 @@ def main():
         e1.synchronize()
         copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
+
+    out = None
     if rank == 0:
-        # dominant kernel of the iteration and its HBM roofline position
-        kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
-        kms = tm[kern + "_ms"]
-        kname = {0: "phi_pass_kernel", 2: "phi_pass_packed_kernel<codec_f48>", 3: "phi_pass_packed_kernel<codec_p59>"}.get(wi["w_layout"], "phi pass")
-        kname, kbytes = f"{kname} ({kern} pass)", ab[kern]
-        graph = kms == 0
-        if graph:
-            # launch-bound workload: hpf_iterate replayed the iteration as one
-            # hipGraph, so only the whole iteration is timed
-            kms = tm["iteration_ms"]
-            kname, kbytes = "whole iteration (hipGraph replay)", ab["phi_user"] + ab["phi_item"] + ab["rows"]
-        achieved = kbytes / (kms * 1e-3) / 1e9
-        traffic, traffic_note = (None, "custom workload") if custom or world > 1 else measured_traffic(cname, kern)
-        # What bounds the kernel.  `traffic` is what crossed from the fabric
-        # into the XCDs' L2s (FETCH_SIZE counts Infinity-Cache hits too): when that rate is above
-        # what a device copy reaches on this GPU, part of it was served by the Infinity Cache and
-        # the pass is bound by the rate at which L2 misses are filled, not by DRAM alone.
-        fabric_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
-        hbm_only, hbm_only_note = measured_traffic("C3", "phi_item_hbm_only_GBps")
-        if fabric_gbs and copy_gbs and fabric_gbs > copy_gbs:
-            bound = "fabric request rate (HBM + Infinity Cache)"
-        else:
-            bound = "hbm"
-        # bytes the sweeps really move: read the raw sums, write W (16 B per element);
-        # SURVEY.md's formula credits 32 (it assumes shape, rate, E and Elog all materialised)
-        Kp = K + (1 if cfg["bias"] else 0)
-        rows_moved = (n_loc + m) * Kp * 16
-
-        def gbs(b, ms):
-            return round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
-
-        per_kernel = None if graph else {
-            "phi_item": {"algorithmic_bytes": ab["phi_item"], "ms": round(tm["phi_item_ms"], 4),
-                         "gather_only_ms": (gather_only or {}).get("phi_item"),
-                         "GBps": gbs(ab["phi_item"], tm["phi_item_ms"]),
-                         "note": "gathers rows of the user matrix (>> Infinity Cache): L2-miss fills from HBM"},
-            "phi_user": {"algorithmic_bytes": ab["phi_user"], "ms": round(tm["phi_user_ms"], 4),
-                         "gather_only_ms": (gather_only or {}).get("phi_user"),
-                         "GBps": gbs(ab["phi_user"], tm["phi_user_ms"]),
-                         "note": "CACHE-INCLUSIVE: its gathers of item rows are largely served by L2 / Infinity "
-                                 "Cache, so this figure may exceed the HBM peak; it is not an HBM rate"},
-            "sweeps": {"bytes_moved": rows_moved, "survey_formula_bytes": ab["rows"],
-                       "ms": round(tm["sweep_user_ms"] + tm["sweep_item_ms"], 4),
-                       "GBps_moved": gbs(rows_moved, tm["sweep_user_ms"] + tm["sweep_item_ms"]),
-                       "note": "fp64-VALU-bound (digamma + exp per element), not HBM-bound"},
-        }
         flags = " ".join(f for f, on in (("-hier", cfg["hier"]), ("-bias", cfg["bias"]),
                                          ("-binary-data", cfg["binary"])) if on)
         if strong:
@@ -531,6 +656,10 @@ def main():
             "unit": "rating-nonzeros/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # the median of the hipEvent-timed iterations, beside the wall-clock mean
+            # `value` is computed from (this rank's handle; N > 1: rank 0's)
+            "ms_per_step_median_hipevent": float(np.median(it_ms)) if it_ms.size else None,
+            "ms_per_step_hipevent_min_max": [float(it_ms.min()), float(it_ms.max())] if it_ms.size else None,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else
                      "f64 arithmetic, W stored in 48 bits (opt-in mode)" if args.w48 else "f64", "data": "synthetic",
@@ -542,45 +671,11 @@ def main():
                              f"({m * ld_x * 8 / 1e6:.0f} MB) all-reduced once per iteration underneath the user half")
                 if use_dist else "single GPU",
             },
-            "roofline": {
-                "bound": bound, "kernel": kname,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
-                "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
-                "traffic": traffic, "traffic_source": traffic_note,
-                # traffic / launch time: cache-inclusive (Infinity-Cache hits are counted by FETCH_SIZE)
-                "fabric_side_GBps": fabric_gbs,
-                # the same kernel where nothing it gathers can be cache-resident (whole C3: 9 GB of
-                # user rows, uniform degrees), algorithmic bytes / time, from the profile named
-                "hbm_only_frac": (hbm_only / HBM_PEAK_GBS) if hbm_only else None,
-                "hbm_only_source": hbm_only_note if hbm_only else "no DRAM-side counter in rocprofv3 -L on gfx950; "
-                                   "no whole-C3 profile of this kernel source in profiles/traffic.json",
-                "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
-                # the same pass with the arithmetic taken out: what the memory system needs for its
-                # gathers alone.  frac_of_gather_only = that time / the pass's time
-                "gather_only_ms": (gather_only or {}).get(kern),
-                "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
-                # rows of W as stored: plain fp64 (8 B per element) or the LOSSLESS 59-bit packing the
-                # library picks where it saves a 128-byte line per row; the algorithmic bytes above
-                # use the stored element size, so they never exceed what has to move
-                "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)"}.get(wi["w_layout"]),
-                # tiled pass: the nonzeros of the heavy rows are regrouped by 3 MiB tile of
-                # the gathered matrix and a tile's segments run on one XCD, out of its L2.  `achieved` stays
-                # ALGORITHMIC bytes / time (every gathered row counted once per nonzero), so with tiling it can
-                # pass the HBM peak: the tiled share of those bytes never crosses the fabric -- `traffic` shows it
-                "frac_note": ("frac > 1: `achieved` counts every gathered row once per nonzero (the contract's algorithmic "
-                              "bytes); the tiled share of those rows is served by the XCDs' L2s, so fewer bytes than that "
-                              "cross the fabric -- see `traffic` and `fabric_side_GBps`") if achieved > HBM_PEAK_GBS else None,
-                "tiles": {"phi_item": wi["tiles_item"], "phi_user": wi["tiles_user"],
-                          "note": "0 = row-major pass; >0 = heavy rows regrouped by that many tiles of the gathered rows"},
-                "hbm_copy_measured_GBps": copy_gbs,
-                "per_kernel": per_kernel,
-            },
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
             "work": {k: wi[k] for k in ("user_segments", "item_segments", "user_long_rows", "item_long_rows",
                                         "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R", "ld", "w_layout",
-                                        "tiles_user", "tiles_item")},
+                                        "tiles_user", "tiles_item", "tile_rows_user", "tile_rows_item",
+                                        "heavy_min_nnz_user", "heavy_min_nnz_item")},
             "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
             # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user
@@ -597,14 +692,15 @@ def main():
             out["compute_ms"] = {"max": max(comp), "min": min(comp)}
         if rccl is not None:
             out["rccl"] = rccl
-        if world == 1 and not custom and not force_dist and (n_loc + m) * wi["ld"] * 8 * 5 + nnz_loc * 12 < 0.4 * free_b:
+        if (world == 1 and not custom and not force_dist and not args.lean
+                and (n_loc + m) * wi["ld"] * 8 * 5 + nnz_loc * 12 < 0.4 * free_b):
             # context, never `value`: the same workload with W stored in 48 bits (hpf_config.w_storage = 2,
             # opt-in): the passes are bound by bytes per gathered row, this is what shorter rows buy
             try:
                 D2 = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
                          stream=stream.cuda_stream, w_storage=2)
                 D2.upload_csr_device(rowptr, col, val)
-                start_state(D2, n_loc, row0, ss)
+                start_state(D2, cfg, n_loc, row0, ss, n_total, dev)
                 D2.iterate(2)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -624,14 +720,15 @@ def main():
                     "default_row_bytes": wi["phi_G"] * wi["phi_R"] * (16 if wi["w_layout"] else 8 * wi["phi_V"])}
             except Exception as ex:
                 out["w48_opt_in"] = {"error": str(ex)}
-        if world == 1 and not args.no_cpu_baseline and not force_dist:
-            s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
-            s_users = min(s_users, n_loc)
-            nz = int(rowptr[s_users])
-            out["cpu_baseline"] = cpu_baseline(cfg, rowptr[: s_users + 1].cpu().numpy(),
-                                               col[:nz].cpu().numpy().view(np.uint32),
-                                               None if val is None else val[:nz].cpu().numpy())
+    cpu_slice = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not force_dist:
+        s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
+        s_users = min(s_users, n_loc)
+        nz = int(rowptr[s_users])
+        cpu_slice = (rowptr[: s_users + 1].cpu().numpy(), col[:nz].cpu().numpy().view(np.uint32),
+                     None if val is None else val[:nz].cpu().numpy())
     D.close()
+    one_gpu = None
     if rank == 0 and strong and not args.no_1gpu_reference:
         # the SAME matrix, whole, on this rank's GPU, timed by the same clock in the same
         # process: the strong-scaling ratio then rests on nothing stored
@@ -650,7 +747,7 @@ def main():
             D1.upload_csr_device(rp1, c1, v1)
             nnz1 = int(rp1[-1])
             del rp1, c1, v1
-            start_state(D1, n_total, 0, cfg["seed"])
+            start_state(D1, cfg, n_total, 0, cfg["seed"], n_total, dev)
             steps1 = max(2, min(args.steps, 5))
             D1.iterate(2)
             torch.cuda.synchronize()
@@ -660,14 +757,125 @@ def main():
             ms1 = (time.perf_counter() - t0) / steps1 * 1e3
             tm1 = D1.mean_timing(steps1)
             D1.close()
-            out["speedup_vs_1gpu_same_workload"] = {
+            one_gpu = {
                 "value": ms1 / out["ms_per_step"], "one_gpu_ms_per_step": ms1, "one_gpu_nnz": nnz1,
                 "one_gpu_kernels_ms": {k: round(v, 3) for k, v in tm1.items() if k.endswith("_ms")},
                 "source": f"same run: rank 0 timed {steps1} iterations of the whole matrix on its own GPU after the "
                           "timed region (the other ranks wait)"}
         except Exception as ex:
-            out["speedup_vs_1gpu_same_workload"] = {"value": None, "source": f"same-run reference failed: {ex}"}
+            one_gpu = {"value": None, "source": f"same-run reference failed: {ex}"}
+        out["speedup_vs_1gpu_same_workload"] = one_gpu
+    elif rank == 0:
+        del rowptr, col, val
+        torch.cuda.empty_cache()
+
     if rank == 0:
+        # ---- the other BASELINE shapes on this GPU (outside `value`; a few seconds each)
+        if world == 1 and not custom and not force_dist and not args.no_other_configs and cname == "C2":
+            out["other_configs"] = {"note": "outside `value`: other BASELINE shapes timed in this same run on this GPU "
+                                            "(5 iterations after 2 warm-up; wall clock and the library's hipEvents)"}
+            for label, base, over in OTHER_CONFIGS:
+                out["other_configs"][label] = side_config(base, dict(over), dev, local_rank, stream)
+                log(f"[other_configs] {label}: {out['other_configs'][label].get('ms_per_step')} ms/step "
+                    f"({out['other_configs'][label].get('seconds')} s)")
+
+        # ---- roofline of the dominant kernel.  `frac` is the MEMORY-SIDE fraction: bytes that crossed from
+        # the fabric into the XCDs' L2s per launch (PMC counters read in this run) / launch time / HBM peak.
+        kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
+        kms = tm[kern + "_ms"]
+        kname = {0: "phi_pass_kernel", 2: "phi_pass_packed_kernel<codec_f48>", 3: "phi_pass_packed_kernel<codec_p59>"}.get(wi["w_layout"], "phi pass")
+        kname, kbytes = f"{kname} ({kern} pass)", ab[kern]
+        graph = kms == 0
+        if graph:
+            # launch-bound workload: hpf_iterate replayed the iteration as one
+            # hipGraph, so only the whole iteration is timed
+            kms = tm["iteration_ms"]
+            kname, kbytes = "whole iteration (hipGraph replay)", ab["phi_user"] + ab["phi_item"] + ab["rows"]
+        alg_gbs = kbytes / (kms * 1e-3) / 1e9
+        traffic = None
+        pmc = None
+        traffic_note = "custom workload" if custom else "multi-GPU run" if world > 1 else "--lean / --no-pmc"
+        if world == 1 and not force_dist and not args.no_pmc and not graph:
+            wl = (["--config", cname] + [x for k in ("n", "m", "nnz", "K") if getattr(args, k) for x in (f"--{k}", str(getattr(args, k)))]
+                  + (["--scale", str(args.scale)] if args.scale != 1.0 else []) + (["--w48"] if args.w48 else []) + (["--w32"] if args.w32 else []))
+            per, cal, traffic_note = pmc_passes(wl, max(n_loc, m), wi["ld"])
+            if per:
+                fcal = cal.get("fetch_x2_over_known_read") or 1.0
+                fcal = fcal if 0.9 < fcal < 1.25 else 1.0                 # a calibration outside that band is not one
+                tr = {}
+                for sd, nm in ((0, "phi_user"), (1, "phi_item")):
+                    tr[nm] = int(2.0 * per[sd]["FETCH_SIZE"] * 1024.0 / fcal + per[sd]["WRITE_SIZE"] * 1024.0)
+                traffic = tr[kern]
+                pmc = {"per_launch_bytes": tr, "FETCH_SIZE_KiB": {"phi_user": per[0]["FETCH_SIZE"], "phi_item": per[1]["FETCH_SIZE"]},
+                       "WRITE_SIZE_KiB": {"phi_user": per[0]["WRITE_SIZE"], "phi_item": per[1]["WRITE_SIZE"]},
+                       "launches_averaged": per[1].get("launches"), "calibration": cal, "fetch_calibration_applied": fcal,
+                       "formula": "bytes = 2 x FETCH_SIZE x 1024 / fetch_calibration + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE counts 128-B "
+                                  "requests at 64 B; Infinity-Cache hits are included: no DRAM-side counter exists)"}
+        if traffic is None and not custom and world == 1:
+            stored, note2 = measured_traffic(cname, kern)            # labelled fallback: a stored profile of the same kernel source
+            if stored:
+                traffic, traffic_note = stored, f"STORED, not this run ({traffic_note}): {note2}"
+        mem_gbs = traffic / (kms * 1e-3) / 1e9 if traffic else None
+        # bytes the sweeps really move: read the raw sums, write W (16 B per element);
+        # SURVEY.md's formula credits 32 (it assumes shape, rate, E and Elog all materialised)
+        Kp = K + (1 if cfg["bias"] else 0)
+        rows_moved = (n_loc + m) * Kp * 16
+
+        def gbs(b, ms):
+            return round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+
+        per_kernel = None if graph else {
+            "phi_item": {"algorithmic_bytes": ab["phi_item"], "ms": round(tm["phi_item_ms"], 4),
+                         "gather_only_ms": (gather_only or {}).get("phi_item"),
+                         "algorithmic_GBps": gbs(ab["phi_item"], tm["phi_item_ms"]),
+                         "memory_side_bytes": pmc["per_launch_bytes"]["phi_item"] if pmc else None,
+                         "memory_side_GBps": gbs(pmc["per_launch_bytes"]["phi_item"], tm["phi_item_ms"]) if pmc else None,
+                         "note": "gathers rows of the user matrix (>> Infinity Cache): L2-miss fills from HBM"},
+            "phi_user": {"algorithmic_bytes": ab["phi_user"], "ms": round(tm["phi_user_ms"], 4),
+                         "gather_only_ms": (gather_only or {}).get("phi_user"),
+                         "algorithmic_GBps": gbs(ab["phi_user"], tm["phi_user_ms"]),
+                         "memory_side_bytes": pmc["per_launch_bytes"]["phi_user"] if pmc else None,
+                         "memory_side_GBps": gbs(pmc["per_launch_bytes"]["phi_user"], tm["phi_user_ms"]) if pmc else None,
+                         "note": "its gathers of item rows are largely served by L2 / Infinity Cache: the algorithmic figure is "
+                                 "CACHE-INCLUSIVE and may exceed the HBM peak; the memory-side one counts Infinity-Cache hits too"},
+            "sweeps": {"bytes_moved": rows_moved, "survey_formula_bytes": ab["rows"],
+                       "ms": round(tm["sweep_user_ms"] + tm["sweep_item_ms"], 4),
+                       "GBps_moved": gbs(rows_moved, tm["sweep_user_ms"] + tm["sweep_item_ms"]),
+                       "note": "fp64-VALU-bound (digamma + exp per element), not HBM-bound"},
+        }
+        hbm_only, hbm_only_note = measured_traffic("C3", "phi_item_hbm_only_GBps")
+        out["roofline"] = {
+            "bound": "hbm", "kernel": kname,
+            # memory side: what crossed the fabric into the L2s per launch / launch time.  <= peak by construction
+            # of the machine; when the counters are unavailable the ALGORITHMIC rate stands in and says so
+            "achieved": mem_gbs if mem_gbs else alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (mem_gbs if mem_gbs else alg_gbs) / HBM_PEAK_GBS,
+            "frac_basis": "memory-side traffic (PMC counters) / launch time / peak" if mem_gbs else
+                          "ALGORITHMIC bytes / launch time / peak (no counters in this run): cache-inclusive, may exceed 1",
+            "traffic": traffic, "traffic_source": traffic_note,
+            "avg_launch_ms": kms,
+            "frac_of_achievable": (mem_gbs / HBM_ACHIEVABLE_GBS) if mem_gbs else None,
+            "frac_of_measured_copy": (mem_gbs / copy_gbs) if mem_gbs and copy_gbs else None,
+            "hbm_copy_measured_GBps": copy_gbs,
+            # the contract's ALGORITHMIC bytes (every gathered row counted once per nonzero, at its stored
+            # size) / launch time.  Cache-inclusive: the tiled share of those rows is served by the XCDs' L2s and never
+            # crosses the fabric, so this may exceed the HBM peak -- it is a throughput figure, not a roofline fraction
+            "algorithmic_bytes_per_launch": kbytes, "algorithmic_GBps": alg_gbs, "algorithmic_over_peak": alg_gbs / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": (traffic / kbytes) if traffic else None,
+            "pmc": pmc,
+            # the same kernel where nothing it gathers can be cache-resident (whole C3, row-major): a stored profile
+            "hbm_only_frac": (hbm_only / HBM_PEAK_GBS) if hbm_only else None,
+            "hbm_only_source": hbm_only_note if hbm_only else None,
+            # the same pass with the arithmetic taken out: what the memory system needs for its gathers alone
+            "gather_only_ms": (gather_only or {}).get(kern),
+            "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
+            "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)"}.get(wi["w_layout"]),
+            "tiles": {"phi_item": wi["tiles_item"], "phi_user": wi["tiles_user"],
+                      "note": "0 = row-major pass; >0 = heavy rows regrouped by that many tiles of the gathered rows"},
+            "per_kernel": per_kernel,
+        }
+        if cpu_slice is not None:
+            out["cpu_baseline"] = cpu_baseline(cfg, *cpu_slice)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -39,6 +39,7 @@ EXPORTS = [
     "hpf_algorithmic_bytes",
     "hpf_snapshot_size", "hpf_snapshot_save", "hpf_snapshot_load",
     "hpf_get_work_info", "hpf_upload_csr_device", "hpf_get_csc", "hpf_set_state_device", "hpf_get_state_device",
+    "hpf_iteration_times", "hpf_debug_poke_index", "hpf_start_sums",
 ]
 
 
@@ -71,6 +72,8 @@ class HpfWorkInfo(C.Structure):
         ("phi_G", C.c_uint32), ("phi_R", C.c_uint32), ("phi_V", C.c_uint32),
         ("sweep_G", C.c_uint32), ("sweep_R", C.c_uint32), ("ld", C.c_uint32),
         ("graph_replay", C.c_uint32), ("w_layout", C.c_uint32), ("tiles_user", C.c_uint32), ("tiles_item", C.c_uint32),
+        ("tile_rows_user", C.c_uint32), ("tile_rows_item", C.c_uint32),
+        ("heavy_min_nnz_user", C.c_uint64), ("heavy_min_nnz_item", C.c_uint64),
     ]
 
 
@@ -125,6 +128,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_iterate.argtypes = [vp, C.c_int]
     lib.hpf_iterate_local.argtypes = [vp]
     lib.hpf_iterate_global.argtypes = [vp]
+    lib.hpf_start_sums.argtypes = [vp]
     lib.hpf_iterate_local_phi.argtypes = [vp]
     lib.hpf_iterate_local_items.argtypes = [vp]
     lib.hpf_iterate_local_users.argtypes = [vp]
@@ -150,6 +154,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
     lib.hpf_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]
+    lib.hpf_iteration_times.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), u32p]
+    lib.hpf_debug_poke_index.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint32, u32p, u32p]
     if path is None:
         _lib = lib
     return lib
@@ -179,6 +185,7 @@ class Hpf:
         cfg.tiling = int(tiling)             # 0: the library decides (tiled phi pass where it pays), 1: never
         self.n_users, self.n_items, self.K = int(n_users), int(n_items), int(K)
         self.hier, self.bias, self.binary = bool(hier), bool(bias), bool(binary)
+        self.n_ranks = int(n_ranks)
         self.device = int(device)            # the HIP ordinal every device pointer handed in must live on
         self._h = C.c_void_p()
         rc = self.lib.hpf_create(C.byref(cfg), C.byref(self._h))
@@ -333,6 +340,11 @@ class Hpf:
     def iterate_global(self):
         self._check(self.lib.hpf_iterate_global(self._h))
 
+    def start_sums(self):
+        """-novb on several ranks: leave this rank's sum_u E[theta] of the start state in the tail of the
+        exchange buffer (the caller all-reduces its last ld doubles unless hpf_comm_init was done)"""
+        self._check(self.lib.hpf_start_sums(self._h))
+
     def exchange_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self.lib.hpf_exchange_buffer(self._h, C.byref(p), C.byref(n)))
@@ -455,6 +467,19 @@ class Hpf:
         t = HpfTiming()
         self._check(self.lib.hpf_mean_timing(self._h, int(n_last), C.byref(t)))
         return {f: getattr(t, f) for f, _ in HpfTiming._fields_}
+
+    def iteration_times(self, n_last: int) -> np.ndarray:
+        """iteration_ms of each of the last n_last iterations (hipEvents), oldest first"""
+        out = np.zeros(max(int(n_last), 1), np.float32)
+        got = C.c_uint32(0)
+        self._check(self.lib.hpf_iteration_times(self._h, int(n_last), _ptr(out, C.c_float), C.byref(got)))
+        return out[: got.value].astype(np.float64)
+
+    def debug_poke_index(self, side: int, pos: int, value: int):
+        """TEST HOOK: overwrite one entry of the index stream of a phi pass -> (old value, owner row)"""
+        old, own = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.lib.hpf_debug_poke_index(self._h, int(side), int(pos), int(value), C.byref(old), C.byref(own)))
+        return old.value, own.value
 
     def snapshot(self) -> np.ndarray:
         """the loop's device state as one opaque blob (uint8 array)"""

@@ -71,6 +71,7 @@ int Env::parse(int argc, char **argv, bool echo, std::string *bad)
     else if (!strcmp(s, "-device")) { device = atoi(next()); device_set = true; }   // extension: HIP device ordinal
     else if (!strcmp(s, "-ngpus")) { ngpus = atoi(next()); if (ngpus < 1) ngpus = 1; } // extension: one process per GPU
     else if (!strcmp(s, "-comm")) { comm_mode = next(); }            // extension: rccl | host
+    else if (!strcmp(s, "-single-allreduce")) { single_allreduce = true; }  // extension: one fused all-reduce per iteration
     else if (!strcmp(s, "-checkpoint")) { checkpoint_every = (uint32_t)atoi(next()); }   // extension
     else if (!strcmp(s, "-resume")) { resume = true; }                                 // extension
     else if (!strcmp(s, "-cache")) { data_cache = true; }                              // extension

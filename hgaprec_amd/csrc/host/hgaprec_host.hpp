@@ -33,6 +33,8 @@ struct Env {
   bool plain_rows = false;              // -plain-rows: keep W in plain fp64 rows (for states with an Elog spread > 88 inside a row)
   int ngpus = 1;
   std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)
+  bool single_allreduce = false;        // -single-allreduce: ONE all-reduce of [m x ld | ld] per iteration after the user half, as
+                                        // BASELINE.json words it, instead of the overlapped pair (item sums underneath the user half + tail)
   // extension (the reference has no training resume: its -load is inert,
   // main.cc:137-140): -checkpoint N writes <outdir>/checkpoint.r<rank>of<world>.bin
   // every N iterations, -resume continues from it

@@ -88,6 +88,7 @@ struct hpf_handle {
   // item rate is built from the sum_u E[theta] of BEFORE this iteration's user sweep
   bool jacobi = false;
   double *u_colsum_prev = nullptr;      // [ld]
+  bool start_sums_done = false;         // jacobi on several ranks: the start state's sum_u E[theta] has been handed to the exchange
   // One GPU, problems too large for the graph replay: the user sweep runs on a second stream
   // UNDERNEATH the item-major phi pass (iterate_overlapped).  The item pass still reads the W of
   // the users, so the sweep writes the new one into a spare buffer and the two are swapped.
@@ -1122,6 +1123,7 @@ int prepare_derived(hpf_handle *h)
                        s.colsum_part, nb, h->ld, s.colsum);
   }
   if (h->jacobi) {      // sum_u E[theta] of the start state: the first item rate uses it
+    h->start_sums_done = false;           // several ranks: this rank's part only, until hpf_start_sums hands it to the exchange
     Side &s = h->u;
     if (!s.have_E) { h->err = "state not initialised: -novb needs THETA_E (the first item rate is built from it)"; return HPF_ERR_STATE; }
     { int rc0 = refresh_es(h, s); if (rc0) return rc0; }
@@ -1212,6 +1214,13 @@ int phi_items(hpf_handle *h)
   int rc;
   if (h->capturing) return run_phi(h, h->it, h->u, nullptr);
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  if (h->jacobi && h->cfg.n_ranks > 1 && (h->derived_dirty || !h->start_sums_done)) {
+    if (h->comm) { if ((rc = hpf_start_sums(h))) return rc; }
+    else if (h->derived_dirty || !h->start_sums_done) {
+      h->err = "-novb on several ranks: call hpf_start_sums and sum-all-reduce the last ld doubles of the exchange buffer before the first iteration";
+      return HPF_ERR_STATE;
+    }
+  }
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
   h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
@@ -1420,7 +1429,6 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (cfg->K == 0 || cfg->n_items == 0) return HPF_ERR_INVALID;
   if (cfg->n_ranks == 0 || cfg->rank >= cfg->n_ranks) return HPF_ERR_INVALID;
   const bool jacobi = cfg->novb && cfg->bias && !cfg->hier;       // the only place the reference reads Env::vb
-  if (jacobi && cfg->n_ranks != 1) return HPF_ERR_UNSUPPORTED;
   const uint32_t C = cfg->K + (cfg->bias ? 2u : 0u);
   if (C > HPF_MAX_COLUMNS) return HPF_ERR_UNSUPPORTED;
   int ndev = 0;
@@ -1717,6 +1725,25 @@ int hpf_allreduce_exchange(hpf_handle *h)
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_reduced, 0));
   h->items_reduce_pending = false;
   return check_comm_async(h);
+}
+
+int hpf_start_sums(hpf_handle *h)
+{
+  if (!h) return HPF_ERR_INVALID;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  int rc;
+  if ((rc = prepare_derived(h))) return rc;
+  if (!h->jacobi || h->cfg.n_ranks == 1) return HPF_OK;
+  if (h->start_sums_done) return HPF_OK;
+  if (h->comm) {                        // the library owns the exchange: the [ld] tail, in place, on the kernels' stream
+    const size_t items = (size_t)h->it.rows * h->ld;
+    const int rc2 = g_rccl.AllReduce(h->exch + items, h->exch + items, h->exch_count - items, 8, 0, h->comm, (void *)h->stream);
+    if (rc2 != 0) { h->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc2); return HPF_ERR_HIP; }
+    if ((rc = check_comm_async(h))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));     // the caller's all-reduce may run on another stream
+  h->start_sums_done = true;
+  return HPF_OK;
 }
 
 int hpf_exchange_read(hpf_handle *h, double *host, size_t count)
@@ -2159,6 +2186,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
   }
   h->derived_dirty = hd.derived_dirty != 0;
+  h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
@@ -2465,6 +2493,8 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->ld = h->ld;
   out->w_layout = (uint32_t)h->wl;
   out->tiles_user = h->u.tiles; out->tiles_item = h->it.tiles;
+  out->tile_rows_user = h->u.tile_rows; out->tile_rows_item = h->it.tile_rows;
+  out->heavy_min_nnz_user = h->u.tiles ? h->u.light_below : 0; out->heavy_min_nnz_item = h->it.tiles ? h->it.light_below : 0;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
 }
@@ -2555,6 +2585,46 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
 }
 
 int hpf_last_timing(hpf_handle *h, hpf_timing *out) { return hpf_mean_timing(h, 1, out); }
+
+int hpf_iteration_times(hpf_handle *h, uint32_t n_last, float *ms_out, uint32_t *n_out)
+{
+  if (!h || !ms_out || !n_out) return HPF_ERR_INVALID;
+  *n_out = 0;
+  const uint32_t n = std::min<uint32_t>(std::min<uint32_t>(n_last, h->ev_count), hpf_handle::RING);
+  if (n == 0) return HPF_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (uint32_t k = 0; k < n; ++k) {                       // oldest first
+    const uint32_t slot = (h->ev_count - n + k) % hpf_handle::RING;
+    float ms = 0.0f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->evr[slot][0], h->evr[slot][6]));
+    ms_out[k] = ms;
+  }
+  *n_out = n;
+  return HPF_OK;
+}
+
+int hpf_debug_poke_index(hpf_handle *h, int side, uint64_t pos, uint32_t value, uint32_t *old_value, uint32_t *owner_row)
+{
+  if (!h || (side != 0 && side != 1)) return HPF_ERR_INVALID;
+  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  Side &own = side ? h->it : h->u, &oth = side ? h->u : h->it;
+  if (pos >= h->nnz || value >= oth.rows) { h->err = "poke: position or value out of range"; return HPF_ERR_INVALID; }
+  uint32_t *arr = own.p_idx ? own.p_idx : own.idx;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  uint32_t old = 0;
+  HIPCHK(h, hipMemcpy(&old, arr + pos, 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(arr + pos, &value, 4, hipMemcpyHostToDevice));
+  if (old_value) *old_value = old;
+  if (owner_row) {                          // the segment that holds the position names its owner
+    std::vector<Seg> segs(own.nseg);
+    if (own.nseg) HIPCHK(h, hipMemcpy(segs.data(), own.segs, (size_t)own.nseg * sizeof(Seg), hipMemcpyDeviceToHost));
+    *owner_row = 0xffffffffu;
+    for (const Seg &sg : segs)
+      if ((uint64_t)sg.start <= pos && pos < (uint64_t)sg.start + sg.len) { *owner_row = sg.row; break; }
+  }
+  drop_graph(h);
+  return HPF_OK;
+}
 
 int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item, uint64_t *rows)
 {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 4
+#define HPF_ABI_VERSION 5
 
 typedef struct hpf_handle hpf_handle;
 
@@ -111,8 +111,8 @@ typedef struct {
                            /* hier (hgaprec.cc:1250,1276-1297) -- both rates   */
                            /* are then built from the PREVIOUS iteration's     */
                            /* expectations before anything is swapped (the     */
-                           /* item rate takes the old sum_u E[theta]).         */
-                           /* n_ranks must be 1 in that mode.                  */
+                           /* item rate takes the old sum_u E[theta]).  On     */
+                           /* several ranks see hpf_start_sums.                */
   uint32_t tiling;         /* 0: the library decides per side whether the phi  */
                            /* pass is tiled (cache blocking of the gathered    */
                            /* rows, one tile per XCD L2) */
@@ -233,6 +233,16 @@ int  hpf_exchange_buffer(hpf_handle *h, void **device_ptr, size_t *count);
 int  hpf_bind_exchange_buffer(hpf_handle *h, void *device_ptr, size_t count);
 /* ... then the replicated item sweep (C, D-item, F) on every rank. */
 int  hpf_iterate_global(hpf_handle *h);
+/* -novb (hpf_config.novb with bias, without hier) on SEVERAL ranks: the first item rate is built
+ * from sum_u E[theta_u,:] of the START state (hgaprec.cc:1281-1282 reads _theta.sum_rows() before
+ * _theta.swap()), which then has to be summed over the ranks once, before the first iteration.
+ * hpf_start_sums derives what the first iteration needs from the state handed in and leaves this
+ * rank's part of that sum in the tail of the exchange buffer (its last `ld` doubles,
+ * hpf_work_info.ld).  With hpf_comm_init done it also all-reduces the tail itself (and hpf_iterate
+ * calls it on its own); otherwise the caller sum-all-reduces those ld doubles in place, like the
+ * per-iteration exchange.  Call it after the last hpf_set_state / hpf_snapshot_load and before the
+ * first hpf_iterate_local_*: iterating without it returns HPF_ERR_STATE.  A no-op elsewhere. */
+int  hpf_start_sums(hpf_handle *h);
 
 /* The library can run that all-reduce itself: RCCL is dlopen'ed on first use
  * (no link-time dependency).  One rank calls hpf_comm_unique_id and ships the
@@ -312,6 +322,10 @@ typedef struct {
   uint32_t w_layout;                 /* rows of W: 0 plain (phi_V elements per load), 3 packed 59-bit (lossless),  */
                                      /* 2 packed 48-bit (w_storage = 2); packed: phi_R = 16-byte pieces per lane   */
   uint32_t tiles_user, tiles_item;   /* tiled phi pass: tiles of the gathered matrix (0: the side is row-major)   */
+  /* ABI v5 */
+  uint32_t tile_rows_user, tile_rows_item;   /* gathered rows per tile of that side's pass (0: row-major)          */
+  uint64_t heavy_min_nnz_user, heavy_min_nnz_item; /* an owner row with at least this many nonzeros is regrouped  */
+                                     /* tile by tile ("heavy"); the others stay row-major in the same launch       */
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 
@@ -322,10 +336,23 @@ int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
  * the model state. */
 int  hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out);
 
+/* TEST HOOK (tests/test_gpu_fullsize.py): overwrite ONE entry of the index stream a phi pass
+ * walks (side 0: user-major, 1: item-major; `pos` indexes the pass's own array -- the tiled copy
+ * when the side is tiled) with `value` (< rows of the gathered side).  Returns the old value and
+ * the owner row whose sum the entry feeds.  A pass over the damaged list still conserves mass
+ * (every phi sums to its rating whichever row was gathered); the sampled-row checks must not
+ * pass.  Never called by the product path. */
+int  hpf_debug_poke_index(hpf_handle *h, int side, uint64_t pos, uint32_t value,
+                          uint32_t *old_value, uint32_t *owner_row);
+
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);
 /* mean over the last n_last iterations (at most 64 are kept); synchronises */
 int  hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out);
+/* iteration_ms of each of the last n_last iterations, oldest first (hipEvents on the
+ * handle's stream: first launch -> last launch of that iteration); *n_out = how many
+ * were written (<= n_last, <= 64).  For a median instead of a mean. */
+int  hpf_iteration_times(hpf_handle *h, uint32_t n_last, float *ms_out, uint32_t *n_out);
 
 /* algorithmic bytes (SURVEY.md section 8d / DESIGN.md) moved by one launch of
  * the two phi passes and of the row sweeps for the uploaded matrix */

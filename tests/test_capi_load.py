@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_functions():
         assert getattr(lib, name) is not None
     hdr = (Path(capi.__file__).resolve().parent.parent / "include" / "hpf.h").read_text()
-    assert lib.hpf_abi_version() == int(re.search(r"#define HPF_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert lib.hpf_abi_version() == int(re.search(r"#define HPF_ABI_VERSION (\d+)", hdr).group(1)) == 5
     assert lib.hpf_strerror(0) == b"ok"
     assert b"device" in lib.hpf_strerror(-2)
 
@@ -37,7 +37,7 @@ def test_config_struct_layout_matches_header():
     # 12 x 4-byte fields, one pointer, two doubles, novb + reserved (ABI v4)
     assert C.sizeof(capi.HpfConfig) == 12 * 4 + 8 + 16 + 8
     assert C.sizeof(capi.HpfTiming) == 36            # 8 floats + the iteration counter
-    assert C.sizeof(capi.HpfWorkInfo) == 8 + 16 * 4
+    assert C.sizeof(capi.HpfWorkInfo) == 8 + 18 * 4 + 2 * 8      # ABI v5: + tile rows and the heavy bars of both sides
 
 
 def test_no_oracle_on_the_product_path():
@@ -76,20 +76,18 @@ def test_cli_usage_and_unknown_option(tmp_path):
     assert r.returncode == 2 and "outside the MI355X hot-path build" in r.stderr
 
 
-def test_cli_takes_novb_on_one_gpu_and_refuses_it_across_ranks(tmp_path):
+def test_cli_takes_novb_on_one_gpu_and_across_ranks(tmp_path):
     """-novb only changes the reference in vb_bias() (-bias without -hier,
     hgaprec.cc:1276-1297): both rate updates there use the previous iteration's
-    expectations.  Round 3 builds that order on one GPU (hpf_config.novb; parity in
-    tests/test_gpu_parity.py and test_gpu_cli.py); across ranks it is still refused
-    loudly, never run in the default order.  With -hier (or without -bias) the
-    reference never reads the flag."""
+    expectations.  Round 3 built that order on one GPU (hpf_config.novb), round 4 across
+    ranks too (the start state's sum_u E[theta] is reduced once, hpf_start_sums; parity in
+    tests/test_gpu_parity.py, test_gpu_cli.py and test_gpu_multi.py).  With -hier (or
+    without -bias) the reference never reads the flag."""
     exe = str(ROOT / "hgaprec_amd" / "hgaprec")
-    r = subprocess.run([exe, "-dir", "x", "-n", "5", "-m", "5", "-k", "2", "-bias", "-novb", "-ngpus", "2"], cwd=tmp_path,
-                       capture_output=True, text=True)
-    assert r.returncode == 2 and "-novb" in r.stderr and "outside the MI355X hot-path build" in r.stderr
-    r = subprocess.run([exe, "-dir", str(tmp_path / "missing"), "-n", "5", "-m", "5", "-k", "2", "-bias", "-novb"],
-                       cwd=tmp_path, capture_output=True, text=True)
-    assert "outside the MI355X hot-path build" not in r.stderr      # accepted (fails later: no GPU / no data)
-    r = subprocess.run([exe, "-dir", str(tmp_path / "missing"), "-n", "5", "-m", "5", "-k", "2", "-hier", "-novb"],
-                       cwd=tmp_path, capture_output=True, text=True)
-    assert "outside the MI355X hot-path build" not in r.stderr      # goes on (and fails later: no GPU / no data)
+    for extra in ([], ["-hier"]):
+        r = subprocess.run([exe, "-dir", str(tmp_path / "missing"), "-n", "5", "-m", "5", "-k", "2", "-bias", "-novb"] + extra,
+                           cwd=tmp_path, capture_output=True, text=True)
+        assert "outside the MI355X hot-path build" not in r.stderr      # accepted (fails later: no GPU / no data)
+    r = subprocess.run([exe, "-dir", str(tmp_path / "missing"), "-n", "5", "-m", "5", "-k", "2", "-bias", "-novb",
+                        "-single-allreduce", "-comm", "host"], cwd=tmp_path, capture_output=True, text=True)
+    assert "unknown option" not in r.stdout and "outside the MI355X hot-path build" not in r.stderr

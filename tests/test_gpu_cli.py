@@ -145,6 +145,7 @@ def test_cli_matches_oracle_run(orc, tmp_path, flags, K, maxit):
     (["-hier", "-bias", "-logl"], 6, 12),
     ([], 5, None),                 # vb(): stop rule -> do_on_stop -> gen_ranking_for_users on every rank
     (["-hier", "-rfreq", "50"], 5, 100),
+    (["-bias", "-novb"], 5, None), # vb_bias()'s else-branch across ranks: the start state's sum_u E[theta] is reduced once (round 4)
 ])
 def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
     """`-ngpus 2`: two processes (here both on GPU 0, all-reduce staged through
@@ -154,7 +155,7 @@ def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
     data = tmp_path / "data"
     write_dataset(data, n, m, 9000, seed=17)
     hier, bias = "-hier" in flags, "-bias" in flags
-    logl = "-logl" in flags
+    logl, novb = "-logl" in flags, "-novb" in flags
     rfreq = 2 if hier else 10
     if "-rfreq" in flags:
         rfreq = int(flags[flags.index("-rfreq") + 1])
@@ -177,7 +178,7 @@ def test_two_process_cli_matches_oracle(orc, tmp_path, flags, K, maxit):
     ref = tmp_path / "oracle_out"
     ref.mkdir()
     orc.run(data, ref, n, m, K, hier=hier, bias=bias, rfreq=rfreq,
-            max_iterations=maxit if maxit is not None else 1000, seed=7, logl=logl)
+            max_iterations=maxit if maxit is not None else 1000, seed=7, logl=logl, novb=novb)
     for f in ("validation.txt", "test.txt"):
         a, b = series(out / f), series(ref / f)
         assert [x[0] for x in a] == [x[0] for x in b] and [x[2] for x in a] == [x[2] for x in b]
@@ -304,6 +305,26 @@ def test_dataset_cache_runs_are_identical(tmp_path):
         ia, va = read_tsv(outs[0] / nm)
         ib, vb = read_tsv(outs[3] / nm)
         assert np.array_equal(ia, ib) and np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(va))
+    # two ranks, -cache and NO image yet: whether the image is there is one decision for the whole
+    # job -- a rank that saw the image rank 0 had just written would skip the hand-over's collectives and leave
+    # the ranks out of step (a hang, or mixed values).  Rank 0 parses, hands over, and writes the image afterwards;
+    # the run must end and give the bits of the two-rank run that loaded the image.
+    import shutil
+    data2 = tmp_path / "data2"
+    shutil.copytree(data, data2)
+    (data2 / "hgaprec.cache.bin").unlink()
+    d = tmp_path / "write2"
+    d.mkdir()
+    base2 = [str(data2) if a == str(data) else a for a in base]
+    r = subprocess.run([str(EXE)] + base2 + ["-cache", "-ngpus", "2", "-device", "0", "-comm", "host"], cwd=d,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = [p for p in d.iterdir() if p.is_dir()][0]
+    log = (out / "infer.log").read_text()
+    assert "-cache: wrote" in log and "-cache: loaded" not in log and (data2 / "hgaprec.cache.bin").exists()
+    assert "[rank 1] ratings handed over by rank 0" in r.stderr
+    for nm in ("htheta.tsv", "hbeta.tsv", "thetarate.tsv", "precision.txt"):
+        assert (out / nm).read_text() == (outs[3] / nm).read_text(), nm
 
 
 def test_c1_movielens_shaped_end_to_end(orc, tmp_path):

@@ -9,6 +9,12 @@ iteration at this size:
  * xi update:  xi_rate == 0.3 + rowsum(E theta),  xi_shape == 0.3 + 0.3 K
  * user sharding: 2 logical ranks (host-summed exchange) == 1 rank to 1e-10
  * bit-identical repeat runs
+ * VALUES of a sample of owner rows (round 4): all of the above are blind to a gather of
+   the wrong row -- a nonzero's phi sums to max(y, 1) whichever row was read -- so the raw
+   phi sums of >= 500 users and >= 50 items (random, last, heaviest, rows cut into several
+   segments, rows at the heavy / light bar and at tile boundaries) are recomputed in fp64
+   from the exported Elog arrays (tests/rowcheck.py) and held to 1e-9; a deliberately
+   damaged index proves the check sees what mass conservation cannot
 C3 (10M x 1M, 1e9 nnz) runs whole and C5 as the real shard one of 8 GPUs owns;
 both are generated, handed over and checked in HBM (hpf_upload_csr_device).
 """
@@ -83,6 +89,47 @@ def test_c2_one_iteration_properties(c2):
     from scipy.special import digamma
     el = D.get_state("THETA_ELOG")[:1000]
     assert np.max(np.abs(el - (digamma(ts[:1000]) - np.log(tr[:1000])))) < 1e-13
+    D.close()
+
+
+def _t(rowptr, col, val, dev):
+    """host CSR (numpy) -> torch tensors on the device, as tests/rowcheck.py takes them"""
+    import torch
+    return (torch.from_numpy(rowptr).to(dev), torch.from_numpy(col.view(np.int32)).to(dev),
+            None if val is None else torch.from_numpy(val).to(dev))
+
+
+def test_c2_sampled_rows_and_a_damaged_index(c2):
+    """>= 500 users and >= 50 items of C2 value-checked after one iteration from the known start
+    state; then ONE entry of the tiled item pass's index stream is pointed at another user: mass
+    is still conserved, the owner row's values are not, and the sampled-row check says so."""
+    import torch
+    from tests import rowcheck
+    cfg, rowptr, col, val, st = c2
+    dev = torch.device("cuda", 0)
+    rp, c, v = _t(rowptr, col, val, dev)
+    D = _make(cfg, rowptr, col, val, st)
+    wi = D.work_info()
+    assert wi["tiles_item"] > 1 and wi["tile_rows_item"] > 0 and wi["heavy_min_nnz_item"] > 0, wi
+    r = rowcheck.check_handle(D, rp, c, v, n_users=500, n_items=50, seed=1)
+    assert r["rows_checked"]["users"] >= 500 and r["rows_checked"]["items"] >= 50
+    assert r["ok"], r
+    print("C2 sampled rows:", r)
+    # the last position of the tiled array: the last heavy item's run inside the last tile of users
+    nnz = int(rowptr[-1])
+    old, owner = D.debug_poke_index(1, nnz - 1, 0)
+    D.debug_poke_index(1, nnz - 1, old)
+    wrong = (old + 123457) % cfg["n"]
+    D.debug_poke_index(1, nnz - 1, wrong)
+    assert owner < cfg["m"] and int((col == owner).sum()) >= wi["heavy_min_nnz_item"]       # a heavy item's tiled run
+    bad = rowcheck.check_handle(D, rp, c, v, users=[0, 1], items=[owner, 0])
+    assert not bad["ok"] and bad["worst_row"] == ["item", owner] and bad["max_rel_err"] > 1e-7, bad
+    bs = D.get_state("BETA_SHAPE")
+    mass = float(np.maximum(val, 1).astype(np.float64).sum())
+    assert abs((bs - 0.3).sum() - mass) / mass < 1e-11                                      # mass conservation is blind to it
+    D.debug_poke_index(1, nnz - 1, old)
+    good = rowcheck.check_handle(D, rp, c, v, users=[0, 1], items=[owner, 0])
+    assert good["ok"], good
     D.close()
 
 
@@ -173,6 +220,12 @@ def test_c4_bias_k200_properties():
     ts2 = D.get_state("THETA_SHAPE")
     tot = (ts2 - 0.3).sum() + (D.get_state("UBIAS_SHAPE") - 0.3).sum() + (D.get_state("IBIAS_SHAPE") - 0.3).sum()
     assert abs(tot - mass) / mass < 1e-11
+    # values of a sample of rows, bias slots included (both sides of C4 are tiled)
+    from tests import rowcheck
+    del ts, bs, ts2, tr, want
+    r = rowcheck.check_handle(D, *_t(rowptr, col, val, dev), bias=True, n_users=500, n_items=50, seed=2)
+    print("C4 sampled rows:", r, D.work_info())
+    assert r["ok"], r
     D.close()
 
 
@@ -266,6 +319,11 @@ def test_c3_whole_properties():
         wi = D.work_info()
         tm = D.mean_timing(1)
         out = (D.get_state_device("THETA_E", dev), D.get_state_device("BETA_E", dev))
+        if check:            # values of a sample of rows (a third iteration; `out` is already taken)
+            from tests import rowcheck
+            r = rowcheck.check_handle(D, rowptr, col, val, n_users=500, n_items=50, seed=3)
+            print("C3 whole sampled rows:", r)
+            assert r["ok"], r
         D.close()
         torch.cuda.empty_cache()
         return out, wi, tm
@@ -350,6 +408,10 @@ def test_c5_shard_full_size():
         assert float(((got - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
         assert abs(float(got.sum()) - nnz) / nnz < 1e-11
         del bs, got
+    from tests import rowcheck
+    r = rowcheck.check_handle(D, rowptr, col, None, n_users=500, n_items=50, seed=4)
+    print("C5 shard sampled rows:", r, wi)
+    assert r["ok"], r
     tm = D.mean_timing(1)
     print(f"C5 shard 0 of 8: users [{a}, {b}), {nnz} nnz, {wi['item_huge_rows']} huge item rows, "
           f"{tm['iteration_ms']:.1f} ms/iteration (phi item {tm['phi_item_ms']:.1f} + combine "
@@ -387,6 +449,11 @@ def test_more_than_2_31_nonzeros():
         deg_i += torch.bincount(col[a:a + step].to(torch.int64), minlength=m)
     assert float((((bs - 0.3).sum(1) - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
     assert abs(float((ts - 0.3).sum()) - float(rowptr[-1])) / float(rowptr[-1]) < 1e-11
+    del ts, bs
+    from tests import rowcheck
+    r = rowcheck.check_handle(D, rowptr, col, None, n_users=500, n_items=50, seed=5)
+    print(">2^31 nnz sampled rows:", r)
+    assert r["ok"], r
     # the item-major view itself, on a slice: users ascending inside each of the first items
     colptr, users, _ = D.get_csc(int(rowptr[-1]), with_vals=False)
     assert colptr[-1] == int(rowptr[-1]) and np.array_equal(np.diff(colptr), deg_i.cpu().numpy().astype(np.int64))

@@ -8,7 +8,7 @@ held-out log-likelihood to 1e-9 absolute per pair.
 import numpy as np
 import pytest
 
-from tests.util import (compare_states, copy_state, heldout_pairs, make_problem, rel_err)
+from tests.util import (compare_states, copy_state, heldout_pairs, init_states, make_problem, rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,57 @@ def test_vb_bias_novb_uses_the_previous_iterations_sums(orc):
         outs.append((D.get_state("BETA_E"), Mh.state("BETA_E").copy()))
         D.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_vb_bias_novb_across_two_ranks(orc):
+    """the same Jacobi order with the users sharded over two ranks (round 4): the start state's
+    sum_u E[theta] -- what the FIRST item rate is built from -- is summed over the ranks once
+    (hpf_start_sums leaves each rank's part in the tail of its exchange buffer); iterating
+    without that is refused, not run on a partial sum."""
+    from hgaprec_amd.capi import Hpf, HpfError
+    from hgaprec_amd import dist as hd
+    n, m, K = 300, 200, 7
+    rowptr, col, val = make_problem(n, m, 6000, 21)
+    M = orc.Model(n, m, K, False, True, False, novb=True)
+    M.set_csr(rowptr, col, val)
+    M.initialize(21)
+    init = {w: M.state(w).copy() for w in init_states(False, True)}
+    parts = hd.partition_users(rowptr, 2)
+    shards = []
+    for r, (a, b) in enumerate(parts):
+        D = Hpf(b - a, m, K, hier=False, bias=True, novb=True, n_ranks=2, rank=r, n_users_total=n)
+        D.upload_csr(*hd.shard_csr(rowptr, col, val, a, b))
+        hd.scatter_state(D, init, a, b, hier=False)
+        shards.append(D)
+    with pytest.raises(HpfError, match="hpf_start_sums"):
+        shards[0].iterate_local()
+    ld = shards[0].work_info()["ld"]
+    for D in shards:
+        D.start_sums()
+    bufs = [D.exchange_read() for D in shards]
+    tail = bufs[0][-ld:] + bufs[1][-ld:]
+    assert np.allclose(tail[:K], init["THETA_E"].sum(0), rtol=1e-13)
+    for D, x in zip(shards, bufs):
+        x[-ld:] = tail
+        D.exchange_write(x)
+    for it in range(5):
+        M.iterate(1)
+        for D in shards:
+            D.iterate_local()
+        bufs = [D.exchange_read() for D in shards]
+        tot = bufs[0] + bufs[1]
+        for D in shards:
+            D.exchange_write(tot)
+            D.iterate_global()
+        for (a, b), D in zip(parts, shards):
+            for w in compare_states(False, True):
+                want = M.state(w)
+                if w.startswith(("THETA_", "UBIAS_")) and w != "THETA_RATE":
+                    want = want[a:b]
+                e = rel_err(D.get_state(w), want)
+                assert e < RTOL, f"iter {it} rank rows [{a},{b}) {w}: rel err {e:.3e}"
+    for D in shards:
+        D.close()
 
 
 def test_power_law_long_rows_and_singletons(orc):
