@@ -41,6 +41,7 @@ struct Driver {
   uint32_t n, m, k, iter = 0;          // n: ALL users; lo..hi: this rank's range
   uint32_t lo = 0, hi = 0;
   bool use_rccl = false;
+  bool fallback_logged = false;
   time_t start;
   FILE *vf = nullptr, *tf = nullptr, *af = nullptr, *pf = nullptr;
   StopRule stop;
@@ -153,9 +154,11 @@ struct Driver {
     {
       hpf_work_info wi;
       if (root() && hpf_get_work_info(h, &wi) == HPF_OK)      // infer.log: how the device side laid the work out
-        env.lerr("device: rows of W %s, %u columns; phi passes: user %s (%u tiles), item %s (%u tiles)",
-                 wi.w_layout == 3 ? "packed 59-bit (lossless)" : wi.w_layout == 2 ? "48-bit (opt-in)" : "plain fp64", wi.ld,
-                 wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.tiles_item ? "tiled" : "row-major", wi.tiles_item);
+        env.lerr("device: rows of W %s, %u columns; phi passes: user %s (%u tiles%s), item %s (%u tiles%s)",
+                 wi.w_layout == 3 ? "packed 59-bit (lossless)" : wi.w_layout == 2 ? "48-bit (opt-in)" :
+                 wi.w_layout == 4 ? "plain fp64 in 16-byte pieces" : "plain fp64", wi.ld,
+                 wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.w_shadow_item ? ", fp64 shadow of the item rows" : "",
+                 wi.tiles_item ? "tiled" : "row-major", wi.tiles_item, wi.w_shadow_user ? ", fp64 shadow of the user rows" : "");
     }
 
     if (comm.world > 1 && use_rccl) {                      // bootstrap the RCCL communicator
@@ -471,6 +474,16 @@ struct Driver {
 
   void do_on_stop() { save_model(); gen_ranking_for_users(); }          // hgaprec.cc:1572-1577
 
+  // the library moved the rows of W from the packed form to plain doubles (a state p59 cannot hold): say so once
+  void note_fallback() {
+    hpf_work_info wi;
+    if (!fallback_logged && hpf_get_work_info(h, &wi) == HPF_OK && wi.w_fallbacks) {
+      fallback_logged = true;
+      env.lerr("[rank %d] iteration %d: an entry of W fell below 2^-126 of its row maximum; rows of W are plain fp64 from here on "
+               "(results are exact either way)", comm.rank, iter);
+    }
+  }
+
   // HGAPRec::compute_likelihood (hgaprec.cc:1439-1501); returns true to stop
   bool compute_likelihood(bool validation) {
     const HeldOut &ho = validation ? lvalid : ltest;
@@ -574,6 +587,7 @@ struct Driver {
       if (root()) { printf("\r iteration %d", iter); fflush(stdout); }
       if (iter % env.rfreq == 0) {
         if (compute_likelihood(true)) finish(0);
+        note_fallback();
         compute_likelihood(false);
         save_model();
         compute_precision(false);

@@ -32,7 +32,10 @@ namespace {
 struct Side {
   uint32_t rows = 0;
   double *S = nullptr, *E = nullptr, *L = nullptr;
-  void *W = nullptr;                   // [rows x ld] double, or float in the f32-storage mode
+  void *W = nullptr;                   // [rows x ld] double, or float in the f32-storage mode; rows of pieces: [rows x pk.row_bytes]
+  void *W_shadow = nullptr;            // plain-fp64 copy of the rows (pks) that the TILED share of the other side's pass gathers
+  bool shadow_stale = false;           // W is current, the shadow is not (allocated later, or W came with a snapshot)
+  bool w_from_sweep = false;           // W was written by a sweep (a W-only repeat of it restores it), not derived from Elog
   double *prior_E = nullptr, *prior_used = nullptr, *prior_rate = nullptr;
   double *prior_elog = nullptr, *prior_elog_used = nullptr;   // Elog xi/eta now / as used by the last rate
   double *colsum = nullptr;       // [ld] sum over this side's rows of E
@@ -79,7 +82,16 @@ struct hpf_handle {
   int wl = WL_PLAIN;                    // layout of W rows: plain, WL_P59 (lossless packing, default where it shortens
                                         // the row) or WL_F48 (w_storage = 2); packed: phiR = 16-byte pieces per lane
   PackedRow pk = {0, 0, 0, 0, 0};
-  uint32_t *flags = nullptr;            // device word: bit 0 = a softmax denominator underflowed
+  PackedRow pks = {0, 0, 0, 0, 0};      // plain-fp64 rows in pieces for the same columns (codec_f64): the shadow the tiled share reads
+                                        // beside p59 rows -- and what the rows become when p59 cannot hold a state (recover_flush)
+  int sw_mode = SW_PLAIN;               // how the sweep writes W (row_sweep_kernel MODE)
+  bool use_shadow = true;               // HPF_SHADOW=0 (experimental): tiled segments read the packed rows like everything else
+  uint32_t fallbacks = 0;               // automatic moves from p59 rows to plain fp64 rows so far
+  uint32_t notes = 0;                   // hpf_work_info.notes
+  uint64_t iters_counted = 0;           // iterations launched since the device counter flags[1] was last reset
+  bool in_recovery = false;
+  uint32_t *flags = nullptr;            // device words: [0] bit 0 = a softmax denominator underflowed, bit 1 = p59 flushed an entry,
+                                        // bit 2 = passes and sweeps are skipping; [1] = iterations begun (PhiArgs::flags)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   Side u, it;
@@ -89,14 +101,6 @@ struct hpf_handle {
   bool jacobi = false;
   double *u_colsum_prev = nullptr;      // [ld]
   bool start_sums_done = false;         // jacobi on several ranks: the start state's sum_u E[theta] has been handed to the exchange
-  // One GPU, problems too large for the graph replay: the user sweep runs on a second stream
-  // UNDERNEATH the item-major phi pass (iterate_overlapped).  The item pass still reads the W of
-  // the users, so the sweep writes the new one into a spare buffer and the two are swapped.
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  void *u_W_spare = nullptr;
-  bool overlap_sweep = false;           // HPF_OVERLAP=1 (experimental).  Measured at C2: iteration 9.67 -> 9.53 ms, but the
-                                        // item pass beside the sweep takes 5.66 instead of 5.29 ms: off by default
   double *logfact = nullptr;
   int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ranking mask, CSC build)
   int64_t *colptr_dev = nullptr;   // item-major (CSC) column pointers, built on device
@@ -144,7 +148,6 @@ struct hpf_handle {
   bool capturing = false;               // inside stream capture: no events, no counters
   int phase = 0;                        // 0 idle | 1 items pass done | 2 users pass done | 3 user sweep done
   bool ring_graphed[RING] = {};         // slot was a graph replay: only events 0 and 6 exist
-  bool ring_overlapped[RING] = {};      // slot ran iterate_overlapped: user pass first, user sweep beside the item pass
   std::string err;
 };
 
@@ -227,7 +230,7 @@ void dfree(void *p) { if (p) (void)hipFree(p); }
 void free_side(Side &s, bool S_external)
 {
   if (!S_external) dfree(s.S);
-  dfree(s.E); dfree(s.L); dfree(s.W);
+  dfree(s.E); dfree(s.L); dfree(s.W); dfree(s.W_shadow);
   dfree(s.prior_E); dfree(s.prior_used); dfree(s.prior_rate);
   dfree(s.prior_elog); dfree(s.prior_elog_used);
   dfree(s.colsum_used); dfree(s.colsum_part);
@@ -236,6 +239,14 @@ void free_side(Side &s, bool S_external)
   dfree(s.partial); dfree(s.partial2); dfree(s.idx); dfree(s.val);
   dfree(s.p_idx); dfree(s.p_val); dfree(s.chunks);
   s = Side();
+}
+
+// bytes of a side's W: plain rows of ld doubles (floats use half), or rows of 16-byte pieces; never less than one whole
+// row (the packed passes read row 0 of the gathered side even for a segment without nonzeros)
+size_t w_bytes(const hpf_handle *h, uint32_t rows)
+{
+  const size_t row = std::max<size_t>((size_t)h->ld * 8, h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : 0);
+  return (size_t)std::max<uint32_t>(rows, 1u) * row;
 }
 
 // pick (G,R[,V]) with G*R*V >= ld, R <= 8.  Cost = padded row length, +20 % when a lane
@@ -308,31 +319,41 @@ bool launch_phi(bool w32, int G, int R, int V, int side, const PhiArgs &a, uint3
                 : launch_phi_g<double, 1>(G, R, side, a, blocks, st);
 }
 
-template <int G, int WL>
+template <int G, int MODE>
 bool launch_sweep_r(int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, WL>), dim3(blocks), dim3(256), 0, st, a); return true;
+#define SW(RR) case RR: hipLaunchKernelGGL((row_sweep_kernel<G, RR, MODE>), dim3(blocks), dim3(256), 0, st, a); return true;
+  if (MODE == SW_REG_P59) {                  // the slot counts p59 shapes have (p59_of_slots): 6 is none; G = 2 x the pass's lanes <= 64
+    switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(7) SW(8) SW(9) }
+    return false;
+  }
   switch (R) { SW(1) SW(2) SW(3) SW(4) SW(5) SW(6) SW(7) SW(8) }
+  if (MODE == SW_F64 && R == 9) { hipLaunchKernelGGL((row_sweep_kernel<G, 9, MODE>), dim3(blocks), dim3(256), 0, st, a); return true; }
   if (G == 64) switch (R) { SW(9) SW(10) SW(11) SW(12) SW(13) SW(14) SW(15) SW(16) }   // 513..1024 columns
 #undef SW
   return false;
 }
-template <int WL>
+template <int MODE>
 bool launch_sweep_g(int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_sweep_r<4, WL>(R, a, blocks, st);
-    case 8:  return launch_sweep_r<8, WL>(R, a, blocks, st);
-    case 16: return launch_sweep_r<16, WL>(R, a, blocks, st);
-    case 32: return launch_sweep_r<32, WL>(R, a, blocks, st);
-    case 64: return launch_sweep_r<64, WL>(R, a, blocks, st);
+    case 4:  return MODE == SW_REG_P59 ? false : launch_sweep_r<4, MODE == SW_REG_P59 ? SW_PLAIN : MODE>(R, a, blocks, st);
+    case 8:  return launch_sweep_r<8, MODE>(R, a, blocks, st);
+    case 16: return launch_sweep_r<16, MODE>(R, a, blocks, st);
+    case 32: return launch_sweep_r<32, MODE>(R, a, blocks, st);
+    case 64: return launch_sweep_r<64, MODE>(R, a, blocks, st);
   }
   return false;
 }
-bool launch_sweep(int wl, int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_sweep(int mode, int G, int R, const SweepArgs &a, uint32_t blocks, hipStream_t st)
 {
-  return wl == WL_P59 ? launch_sweep_g<WL_P59>(G, R, a, blocks, st)
-       : wl == WL_F48 ? launch_sweep_g<WL_F48>(G, R, a, blocks, st) : launch_sweep_g<WL_PLAIN>(G, R, a, blocks, st);
+  switch (mode) {
+    case SW_REG_P59: return launch_sweep_g<SW_REG_P59>(G, R, a, blocks, st);
+    case SW_LDS_P59: return G == 64 ? launch_sweep_r<64, SW_LDS_P59>(R, a, blocks, st) : false;   // narrower groups build in registers
+    case SW_LDS_F48: return launch_sweep_g<SW_LDS_F48>(G, R, a, blocks, st);
+    case SW_F64:     return launch_sweep_g<SW_F64>(G, R, a, blocks, st);
+  }
+  return launch_sweep_g<SW_PLAIN>(G, R, a, blocks, st);
 }
 
 // packed W rows: G lanes per nonzero, L 16-byte pieces per lane (phi_pass_packed_kernel)
@@ -369,42 +390,107 @@ bool launch_phipk_g(int G, int L, int side, const PhiArgs &a, uint32_t blocks, h
   }
   return false;
 }
+template <int G>
+bool launch_phif64_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  if (L == 9) { launch_phipk_t<codec_f64, G, 9>(side, a, blocks, st); return true; }      // stands in for p59 rows of 17 elements
+  return launch_phipk_l<codec_f64, G>(L, side, a, blocks, st);
+}
 bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
+  if (wl == WL_F64) {
+    switch (G) {
+      case 4:  return launch_phif64_l<4>(L, side, a, blocks, st);
+      case 8:  return launch_phif64_l<8>(L, side, a, blocks, st);
+      case 16: return launch_phif64_l<16>(L, side, a, blocks, st);
+      case 32: return launch_phif64_l<32>(L, side, a, blocks, st);
+      case 64: return launch_phif64_l<64>(L, side, a, blocks, st);
+    }
+    return false;
+  }
   return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, blocks, st) : launch_phipk_g<codec_f48>(G, L, side, a, blocks, st);
 }
 
-template <int G>
-bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+// p59 rows, tiled chunks from the fp64 shadow (phi_pass_mixed_kernel)
+template <int G, int L>
+void launch_phimx_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
-  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) }
-#undef GO
-  return false;
+  if (side & 1) hipLaunchKernelGGL((phi_pass_mixed_kernel<G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
+  else          hipLaunchKernelGGL((phi_pass_mixed_kernel<G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
 }
-bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+template <int G>
+bool launch_phimx_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  switch (G) {
-    case 4:  return launch_gather_only_l<4>(L, a, sink, blocks, st);
-    case 8:  return launch_gather_only_l<8>(L, a, sink, blocks, st);
-    case 16: return launch_gather_only_l<16>(L, a, sink, blocks, st);
-    case 32: return launch_gather_only_l<32>(L, a, sink, blocks, st);
-    case 64: return launch_gather_only_l<64>(L, a, sink, blocks, st);
+  switch (L) {
+    case 1: launch_phimx_t<G, 1>(side, a, blocks, st); return true;
+    case 2: launch_phimx_t<G, 2>(side, a, blocks, st); return true;
+    case 3: launch_phimx_t<G, 3>(side, a, blocks, st); return true;
+    case 4: launch_phimx_t<G, 4>(side, a, blocks, st); return true;
+    case 5: launch_phimx_t<G, 5>(side, a, blocks, st); return true;
+    case 6: launch_phimx_t<G, 6>(side, a, blocks, st); return true;
+    case 7: launch_phimx_t<G, 7>(side, a, blocks, st); return true;
+    case 8: launch_phimx_t<G, 8>(side, a, blocks, st); return true;
   }
   return false;
+}
+bool launch_phi_mixed(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_phimx_l<4>(L, side, a, blocks, st);
+    case 8:  return launch_phimx_l<8>(L, side, a, blocks, st);
+    case 16: return launch_phimx_l<16>(L, side, a, blocks, st);
+    case 32: return launch_phimx_l<32>(L, side, a, blocks, st);
+    case 64: return launch_phimx_l<64>(L, side, a, blocks, st);
+  }
+  return false;
+}
+
+// mixed: the tiled chunks gather rows of (E + 1) / 2 pieces from the shadow, like phi_pass_mixed_kernel (p59 rows only)
+template <int G>
+bool launch_gather_only_l(int L, bool mixed, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+{
+#define GO(LL) case LL: if (mixed) hipLaunchKernelGGL((gather_only_kernel<G, LL, (codec_p59<LL>::E + 1) / 2>), dim3(blocks), dim3(256), 0, st, a, sink); \
+                        else hipLaunchKernelGGL((gather_only_kernel<G, LL, 0>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
+  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) }
+#undef GO
+  if (L == 9 && !mixed) { hipLaunchKernelGGL((gather_only_kernel<G, 9, 0>), dim3(blocks), dim3(256), 0, st, a, sink); return true; }
+  return false;
+}
+bool launch_gather_only(int G, int L, bool mixed, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+{
+  switch (G) {
+    case 4:  return launch_gather_only_l<4>(L, mixed, a, sink, blocks, st);
+    case 8:  return launch_gather_only_l<8>(L, mixed, a, sink, blocks, st);
+    case 16: return launch_gather_only_l<16>(L, mixed, a, sink, blocks, st);
+    case 32: return launch_gather_only_l<32>(L, mixed, a, sink, blocks, st);
+    case 64: return launch_gather_only_l<64>(L, mixed, a, sink, blocks, st);
+  }
+  return false;
+}
+
+int recover_flush(hpf_handle *h, uint32_t fl0, uint32_t begun);
+
+// A sweep (or derive_w) met an element the p59 rows cannot hold: move the handle to plain fp64 rows and repeat
+// whatever the passes skipped since (recover_flush).  Synchronises the stream.  Every consumer outside the hot
+// loop comes through here (or through check_flags) before it touches S, E or W.
+int recover_if_flushed(hpf_handle *h)
+{
+  if (h->in_recovery || h->capturing) return HPF_OK;
+  uint32_t f[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(f, h->flags, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!(f[0] & 2u)) return HPF_OK;
+  return recover_flush(h, f[0], f[1]);
 }
 
 // surfaces a numerical breakdown the kernels flagged (synchronises the stream)
 int check_flags(hpf_handle *h)
 {
+  int rc;
+  if ((rc = recover_if_flushed(h))) return rc;
   uint32_t f = 0;
   HIPCHK(h, hipMemcpyAsync(&f, h->flags, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (f & 2u) {
-    h->err = "an entry of W fell below 2^-126 of its row maximum (Elog spread > 88 inside a row): the packed row layout "
-             "cannot hold it; create the handle with w_storage = 3 (plain fp64 rows; `hgaprec -plain-rows`)";
-    return HPF_ERR_STATE;
-  }
   if (f & 1u) {
     h->err = h->w32 ? "a softmax denominator underflowed to zero: the Elog spread is too wide for f32-stored W; use w_storage = 0"
                     : "a softmax denominator underflowed to zero (Elog spread > ~700): the state is not a valid HPF state";
@@ -771,9 +857,17 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     if ((double)heavy_nnz < h->tile_min_share * (double)nnz) return HPF_OK;
   }
   (void)heavy_rows;
-  {                                                               // room for the temporaries (26 bytes per nonzero)?
+  {
+    // Room for the temporaries (26 bytes per nonzero)?  Decided from what this handle holds and the size of the device, not
+    // from the free memory of the moment: tiling changes the order of a row's sum, and whether a side is tiled
+    // must be a function of the job, not of what else happens to be allocated.  If the allocations fail all the same the
+    // side stays row-major and hpf_work_info.notes says so.
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fr < 40.0 * (double)nnz + (double)(1ull << 30)) return HPF_OK;
+    const double resident = 5.0 * 8.0 * (double)h->ld * ((double)h->u.rows + (double)h->it.rows) + 20.0 * (double)nnz;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && resident + 40.0 * (double)nnz + (double)(1ull << 30) > 0.9 * (double)tot) {
+      h->notes |= (&s == &h->it ? 2u : 1u);
+      return HPF_OK;
+    }
   }
 
   const uint32_t nkeys = tiles + 1;
@@ -941,7 +1035,8 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     for (int x = 0; x < 8; ++x) {
       for (auto &rg : q[x]) {
         const uint32_t ch = chunk_of(rg, CH, CHc);
-        for (uint32_t p0 = rg.first; p0 < rg.second; p0 += std::min(ch, rg.second - p0)) qc[x].push_back(make_uint2(p0, p0 + std::min(ch, rg.second - p0)));
+        const uint32_t tiled_bit = (rg.first >= c0 && rg.second <= c1) ? 0u : 0x80000000u;      // a chunk of runs inside tiles (phi_pass_mixed_kernel)
+        for (uint32_t p0 = rg.first; p0 < rg.second; p0 += std::min(ch, rg.second - p0)) qc[x].push_back(make_uint2(p0, (p0 + std::min(ch, rg.second - p0)) | tiled_bit));
       }
       longest = std::max(longest, qc[x].size());
     }
@@ -971,12 +1066,38 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   for (int k = 0; k < 2; ++k) { dfree(b.K[k]); dfree(b.U[k]); dfree(b.X[k]); dfree(b.V[k]); dfree(sb.K[k]); dfree(sb.U[k]); }
   dfree(key0); dfree(row0); dfree(segs); dfree(longs); dfree(huges); dfree(groups); dfree(partial); dfree(partial2);
   dfree(chunks_dev); dfree(keep_idx); dfree(keep_val);
-  if (rc == HPF_ERR_OOM && !done) {       // tiling is optional: without the room for it the side stays row-major
+  if (rc == HPF_ERR_OOM && !done) {       // tiling is optional: without the room for it the side stays row-major -- and says so
     (void)hipGetLastError();
     h->err.clear();
+    h->notes |= (&s == &h->it ? 8u : 4u);
     rc = HPF_OK;
   }
   return rc;
+}
+
+// The tiled lists of both sides (after device_side_work) and the fp64 shadows they read.  With p59 rows the tiled share of
+// a pass gathers plain doubles (the shadow of the OTHER side's rows): a tile is then 4 MiB of those rows.
+int build_work_lists_tiled(hpf_handle *h, uint64_t nnz)
+{
+  const uint32_t n = h->u.rows, m = h->it.rows;
+  int rc;
+  const bool shadow = h->wl == WL_P59 && h->use_shadow;
+  const size_t rowb = shadow ? (size_t)h->pks.row_bytes : h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : (size_t)h->ld * (h->w32 ? 4 : 8);
+  h->notes &= ~15u;
+  if ((rc = build_tiled_side(h, h->u, h->rowptr_dev, m, nnz, rowb))) return rc;     // the user pass gathers item rows
+  if ((rc = build_tiled_side(h, h->it, h->colptr_dev, n, nnz, rowb))) return rc;
+  Side *own[2] = {&h->u, &h->it}, *oth[2] = {&h->it, &h->u};
+  for (int k = 0; k < 2; ++k) {
+    const bool want = shadow && own[k]->tiles != 0;
+    if (!want) { dfree(oth[k]->W_shadow); oth[k]->W_shadow = nullptr; oth[k]->shadow_stale = false; continue; }
+    if (oth[k]->W_shadow) continue;
+    unsigned char *w = nullptr;
+    if ((rc = dalloc(h, &w, (size_t)std::max<uint32_t>(oth[k]->rows, 1u) * h->pks.row_bytes))) return rc;
+    oth[k]->W_shadow = w;
+    oth[k]->shadow_stale = !oth[k]->w_dirty;       // rows already written: transcode them (prepare_derived)
+    h->derived_dirty = true;
+  }
+  return HPF_OK;
 }
 
 // Item-major view of the ratings, built in HBM: h->u.idx / h->u.val (CSR order)
@@ -1067,6 +1188,7 @@ double host_digamma(double x)
 int refresh_es(hpf_handle *h, Side &s)
 {
   if (!s.es_stale || !s.rows) { s.es_stale = false; return HPF_OK; }
+  { int rc0 = recover_if_flushed(h); if (rc0) return rc0; }       // a repeat of the last sweep needs S as the pass left it
   const size_t ne = (size_t)s.rows * h->ld;
   const uint32_t blocks = (uint32_t)std::min<size_t>((ne + 255) / 256, 8192);
   hipLaunchKernelGGL(materialize_es_kernel, dim3(blocks), dim3(256), 0, h->stream, s.S, s.E, s.prior_used,
@@ -1104,13 +1226,30 @@ int prepare_derived(hpf_handle *h)
     return HPF_ERR_STATE;
   }
   Side *sides[2] = {&h->u, &h->it};
-  for (Side *s : sides) {
-    if (!s->rows || !s->w_dirty) continue;
-    s->w_dirty = false;
-    const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
-    hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
-                       h->wl != WL_PLAIN ? (uint32_t)h->wl : (uint32_t)h->w32,
-                       s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->pk, h->flags);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    bool derived = false;
+    for (Side *s : sides) {
+      if (!s->rows || !s->w_dirty) continue;
+      s->w_dirty = false; s->w_from_sweep = false; s->shadow_stale = false;
+      derived = true;
+      const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
+      hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
+                         h->wl != WL_PLAIN ? (uint32_t)h->wl : (uint32_t)h->w32,
+                         s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->pk, s->W_shadow, h->pks, h->flags);
+    }
+    if (!derived || h->wl != WL_P59 || h->capturing) break;
+    // an Elog spread above 88 inside a row: p59 cannot hold the state -- plain rows then, derived again (recover_flush)
+    uint32_t f[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(f, h->flags, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!(f[0] & 2u)) break;
+    { int rc0 = recover_flush(h, f[0], f[1]); if (rc0) return rc0; }
+  }
+  for (Side *s : sides) {            // a shadow allocated after W was written (a later upload, a snapshot): transcode the rows
+    if (!s->rows || !s->W_shadow || !s->shadow_stale) continue;
+    s->shadow_stale = false;
+    const uint64_t ne = (uint64_t)s->rows * h->pks.G * h->pks.E;
+    hipLaunchKernelGGL(shadow_from_p59_kernel, dim3(grid_for(ne)), dim3(256), 0, h->stream, s->W, h->pk, s->W_shadow, h->pks, s->rows);
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
   {
@@ -1120,7 +1259,7 @@ int prepare_derived(hpf_handle *h)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, h->stream, s.E, s.rows,
                        h->ld, h->K, s.colsum_part);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
-                       s.colsum_part, nb, h->ld, s.colsum);
+                       s.colsum_part, nb, h->ld, s.colsum, h->flags);
   }
   if (h->jacobi) {      // sum_u E[theta] of the start state: the first item rate uses it
     h->start_sums_done = false;           // several ranks: this rank's part only, until hpf_start_sums hands it to the exchange
@@ -1130,12 +1269,20 @@ int prepare_derived(hpf_handle *h)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(s.sweep_blocks), dim3(256), 0, h->stream, s.E, s.rows,
                        h->ld, h->K, s.colsum_part);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
-                       s.colsum_part, s.sweep_blocks, h->ld, s.colsum);
+                       s.colsum_part, s.sweep_blocks, h->ld, s.colsum, h->flags);
   }
   int rc = check_launch(h, "prepare_derived");
   if (rc) return rc;
   h->derived_dirty = false;
   return HPF_OK;
+}
+
+// rows of W in 16-byte pieces?
+bool rows_in_pieces(const hpf_handle *h) { return h->wl != WL_PLAIN; }
+// the tiled chunks of `own`'s pass read the fp64 shadow of the other side
+bool pass_is_mixed(const hpf_handle *h, const Side &own, const Side &oth)
+{
+  return h->wl == WL_P59 && own.chunks && own.tiles && oth.W_shadow;
 }
 
 int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
@@ -1144,61 +1291,63 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
-  a.chunks = own.chunks;
+  a.chunks = own.chunks; a.W_oth_tiled = oth.W_shadow; a.ld = h->ld;
   if (a.nseg) {
     const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-    if (!(h->wl != WL_PLAIN ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
-                 : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream))) {
-      h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
-    }
+    const bool ok = pass_is_mixed(h, own, oth) ? launch_phi_mixed(h->phiG, h->phiR, side, a, blocks, h->stream)
+                  : rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
+                                      : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream);
+    if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
+  } else if (side == 1) {
+    // the item-major pass opens an iteration (phi_pass_skips keeps the books of the fallback protocol): an empty one still does
+    PhiArgs e = a; e.segs = nullptr; e.nseg = 0; e.chunks = nullptr;
+    hipLaunchKernelGGL(phi_open_kernel, dim3(1), dim3(64), 0, h->stream, e);
   }
   // the event separates the phi kernel from the combine that follows it
   if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
-  if (own.ngroup) {                       // level 1 of the very long rows: partial -> partial2
-    const uint32_t blocks = std::min<uint32_t>((own.ngroup + 3) / 4, 16384);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       own.grouprows, own.ngroup, own.partial, own.partial2, h->ld);
-  }
-  if (own.nlong) {
-    const uint32_t blocks = std::min<uint32_t>((own.nlong + 3) / 4, 16384);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       own.longrows, own.nlong, own.partial, own.S, h->ld);
-  }
-  if (own.nhuge) {                        // level 2: partial2 -> S
-    const uint32_t blocks = std::min<uint32_t>((own.nhuge + 3) / 4, 16384);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       own.hugerows, own.nhuge, own.partial2, own.S, h->ld);
-  }
+  // a tiled side's rows carry a partial per tile they meet: a workgroup per row; the cut rows of a row-major list a wave
+  const bool wg = own.tiles != 0 && h->ld <= (uint32_t)HPF_COMBINE_MAXCOLS;
+  auto combine = [&](const LongRow *rows, uint32_t nrows, const double *src, double *dst) {
+    if (wg) hipLaunchKernelGGL(combine_partials_wg_kernel, dim3(std::min<uint32_t>(nrows, 65536)), dim3(256), 0, h->stream,
+                               rows, nrows, src, dst, h->ld, h->flags);
+    else hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 16384)), dim3(256), 0, h->stream,
+                            rows, nrows, src, dst, h->ld, h->flags);
+  };
+  if (own.ngroup) combine(own.grouprows, own.ngroup, own.partial, own.partial2);     // level 1 of the very long rows: partial -> partial2
+  if (own.nlong) combine(own.longrows, own.nlong, own.partial, own.S);
+  if (own.nhuge) combine(own.hugerows, own.nhuge, own.partial2, own.S);              // level 2: partial2 -> S
   return check_launch(h, "phi pass");
 }
 
-// st / W_out: the stream the sweep runs on and the buffer its W goes to (defaults: the handle's
-// stream, the side's W; iterate_overlapped passes a second stream and the spare buffer)
-int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_out, hipStream_t st = nullptr,
-              void *W_out = nullptr)
+// how the sweep of this handle writes W, and the arguments that do not change from launch to launch
+void sweep_args(hpf_handle *h, Side &s, SweepArgs &a)
 {
-  if (!st) st = h->stream;
-  // remember what the rate was built from (export of *_rate.tsv)
-  HIPCHK(h, hipMemcpyAsync(s.colsum_used, colsum_oth, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, st));
-  SweepArgs a;
-  a.S = s.S; a.W = W_out ? W_out : s.W; a.w32 = h->w32;
-  a.pk = h->pk; a.flags = h->flags;
-  s.l_stale = true; s.es_stale = true;
+  a.S = s.S; a.W = s.W; a.w32 = h->w32;
+  a.pk = h->pk; a.pks = h->pks; a.W_shadow = s.W_shadow; a.flags = h->flags;
   a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
-  a.colsum_oth = colsum_oth; a.colsum_part = s.colsum_part;
+  a.colsum_part = s.colsum_part; a.colsum_used = s.colsum_used;
   a.rows = s.rows; a.ld = h->ld; a.K = h->K;
   a.bias_col = s.bias_col; a.junk_col = s.junk_col; a.bias_rate_add = s.bias_rate_add;
   a.s_prior = h->cfg.s_prior; a.r_prior = h->cfg.r_prior; a.hier = h->cfg.hier;
-  if (!launch_sweep(h->wl, h->swG, h->swR, a, s.sweep_blocks, st)) {
+}
+
+int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_out)
+{
+  hipStream_t st = h->stream;
+  SweepArgs a;
+  sweep_args(h, s, a);
+  a.colsum_oth = colsum_oth;                 // the kernel also copies it to colsum_used: what the rate was built from (export of *_rate.tsv)
+  s.l_stale = true; s.es_stale = true; s.w_from_sweep = true; s.shadow_stale = false;
+  if (!launch_sweep(h->sw_mode, h->swG, h->swR, a, s.sweep_blocks, st)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
   if (h->cfg.hier && s.rows)                // xi / eta: E and Elog from the rate the sweep just wrote
     hipLaunchKernelGGL(prior_update_kernel, dim3(std::min<uint32_t>((s.rows + 255) / 256, 4096)), dim3(256), 0, st,
                        s.prior_E, s.prior_used, s.prior_rate, s.prior_elog, s.prior_elog_used, s.rows,
-                       h->cfg.s_prior + (double)h->K * h->cfg.s_prior, a.psi_prior_shape);
+                       h->cfg.s_prior + (double)h->K * h->cfg.s_prior, a.psi_prior_shape, h->flags);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, st,
-                     s.colsum_part, s.sweep_blocks, h->ld, colsum_out);
+                     s.colsum_part, s.sweep_blocks, h->ld, colsum_out, h->flags);
   return check_launch(h, "row sweep");
 }
 
@@ -1214,6 +1363,10 @@ int phi_items(hpf_handle *h)
   int rc;
   if (h->capturing) return run_phi(h, h->it, h->u, nullptr);
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
+  // several ranks: a pass that skipped would leave this rank's sums out of the all-reduce, so the host looks at the flag
+  // before every iteration (one stream synchronisation) and repairs the rows first; one rank lets the passes skip and
+  // catches up at its next synchronisation point (recover_flush)
+  if (h->cfg.n_ranks > 1 && h->wl == WL_P59 && (rc = recover_if_flushed(h))) return rc;
   if (h->jacobi && h->cfg.n_ranks > 1 && (h->derived_dirty || !h->start_sums_done)) {
     if (h->comm) { if ((rc = hpf_start_sums(h))) return rc; }
     else if (h->derived_dirty || !h->start_sums_done) {
@@ -1224,7 +1377,6 @@ int phi_items(hpf_handle *h)
   if ((rc = prepare_derived(h))) return rc;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
   h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
-  h->ring_overlapped[h->ev_count % hpf_handle::RING] = false;
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;   // step A, beta shape sums
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -1292,59 +1444,73 @@ int iterate_global(hpf_handle *h)
   h->phase = 0;
   h->ev_count++;
   h->iterations++;
+  h->iters_counted++;
   return HPF_OK;
 }
 
-// One whole iteration on one GPU with the user sweep hidden under the item-major pass:
-//   main stream:  user pass | ................ item pass ............... | join, swap W | item sweep
-//   side stream:            | user sweep -> spare W, xi, sum_u E[theta]  |
-// Same kernels on the same inputs as iterate_local + iterate_global (the two phi passes are
-// independent of each other and the user sweep reads only what the user pass wrote), so the
-// results are bit-identical; only the order of the two passes and the stream of the sweep differ.
-int iterate_overlapped(hpf_handle *h)
+void drop_graph(hpf_handle *h);
+
+// p59 rows -> plain doubles in the same shape (codec_f64): W reallocated, the shadows dropped, the work lists cut again
+// for the new row size -- exactly what a handle created with w_storage = 3 holds
+int set_rows_f64(hpf_handle *h)
 {
   int rc;
-  if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
-  if (h->phase != 0) { h->err = "call order: an iteration is already in flight"; return HPF_ERR_STATE; }
-  if ((rc = prepare_derived(h))) return rc;
-  if (!h->side_stream) {
-    HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    double *w = nullptr;
-    if ((rc = dalloc(h, &w, (size_t)h->u.rows * h->ld))) {
-      if (rc != HPF_ERR_OOM) return rc;
-      (void)hipGetLastError();                             // no room for the spare matrix: plain sequence from now on
-      h->overlap_sweep = false;
-      if ((rc = iterate_local(h))) return rc;
-      return iterate_global(h);
-    }
-    h->u_W_spare = w;
-    HIPCHK(h, hipStreamSynchronize(h->stream));            // dalloc cleared it on the main stream
+  drop_graph(h);
+  h->wl = WL_F64; h->pk = h->pks; h->phiR = (int)h->pks.L;
+  h->sw_mode = SW_F64;
+  Side *sides[2] = {&h->u, &h->it};
+  for (Side *s : sides) {
+    dfree(s->W); s->W = nullptr; dfree(s->W_shadow); s->W_shadow = nullptr; s->shadow_stale = false;
+    unsigned char *w = nullptr;
+    if ((rc = dalloc(h, &w, w_bytes(h, s->rows)))) return rc;
+    s->W = w;
   }
-  const uint32_t slot = h->ev_count % hpf_handle::RING;
-  h->ev = h->evr[slot];
-  h->ring_graphed[slot] = false; h->ring_overlapped[slot] = true;
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  if ((rc = run_phi(h, h->u, h->it, h->ev[3]))) return rc;             // theta shape sums
-  HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-  if (h->jacobi)
-    HIPCHK(h, hipMemcpyAsync(h->u_colsum_prev, h->u.colsum, (size_t)h->ld * 8, hipMemcpyDeviceToDevice, h->side_stream));
-  if ((rc = run_sweep(h, h->u, h->it.colsum, h->u.colsum, h->side_stream, h->u_W_spare))) return rc;
-  HIPCHK(h, hipEventRecord(h->ev[5], h->side_stream));
-  HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
-  if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;             // beta shape sums, from the OLD W of the users
-  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-  std::swap(h->u.W, h->u_W_spare);
-  HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
-  if ((rc = run_sweep(h, h->it, h->jacobi ? h->u_colsum_prev : h->u.colsum, h->it.colsum))) return rc;
-  HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
-  h->ev_count++;
-  h->iterations++;
+  if (h->have_csr) {
+    if ((rc = device_side_work(h, h->u, h->rowptr_dev, h->u.rows))) return rc;
+    if ((rc = device_side_work(h, h->it, h->colptr_dev, h->it.rows))) return rc;
+    if ((rc = build_work_lists_tiled(h, h->nnz))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return HPF_OK;
+}
+
+// Flag bit 1: an element of W fell below 2^-126 of its row maximum (an Elog spread above 88 inside a row) and the p59
+// rows cannot hold it.  The layout is lossless by contract, and the library holds everything it takes to go on without
+// it: the rows become plain doubles, W is written again -- by a W-ONLY repeat of the side's last sweep (same S, the prior
+// and the column sums that sweep used: the same arithmetic, so the same bits a w_storage = 3 handle has) or by derive_w
+// where W came from a handed-in Elog -- and the iterations the passes skipped in the meantime are run.
+// fl0 / begun: the device's flag word and its count of iterations begun; the stream is synchronised.
+int recover_flush(hpf_handle *h, uint32_t fl0, uint32_t begun)
+{
+  if (h->wl != WL_P59) { h->err = "internal: an entry of W was reported flushed, but the rows are not packed"; return HPF_ERR_STATE; }
+  int rc;
+  h->in_recovery = true;
+  const uint64_t redo = h->iters_counted > (uint64_t)begun ? h->iters_counted - (uint64_t)begun : 0;   // several ranks: none (the host looks every iteration)
+  do {
+    if ((rc = set_rows_f64(h))) break;
+    const uint32_t clear[2] = {fl0 & 1u, 0u};
+    if (hipMemcpyAsync(h->flags, clear, 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "recover_flush: cannot reset the flags"; rc = HPF_ERR_HIP; break; }
+    h->iters_counted = 0;
+    Side *sides[2] = {&h->u, &h->it};
+    for (Side *s : sides) {
+      if (!s->rows) continue;
+      if (!s->w_from_sweep || s->w_dirty) { s->w_dirty = true; h->derived_dirty = true; continue; }     // from Elog: prepare_derived
+      SweepArgs a;
+      sweep_args(h, *s, a);
+      a.prior_E = s->prior_used; a.colsum_oth = s->colsum_used; a.colsum_used = nullptr;             // what that sweep read
+      if (!launch_sweep(h->sw_mode, h->swG, h->swR, a, s->sweep_blocks, h->stream)) { h->err = "no sweep kernel for this configuration"; rc = HPF_ERR_UNSUPPORTED; break; }
+    }
+    if (rc || (rc = check_launch(h, "repeat of the sweeps in plain rows"))) break;
+    h->fallbacks++;
+    if (redo) {
+      if (h->cfg.n_ranks != 1) { h->err = "internal: iterations were skipped on a rank of several"; rc = HPF_ERR_STATE; break; }
+      h->iterations -= (uint32_t)std::min<uint64_t>(redo, h->iterations);
+      for (uint64_t t = 0; t < redo && !rc; ++t) { if (!(rc = iterate_local(h))) rc = iterate_global(h); }
+    }
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "recover_flush: stream error"; rc = HPF_ERR_HIP; }
+  } while (0);
+  h->in_recovery = false;
+  return rc;
 }
 
 void drop_graph(hpf_handle *h)
@@ -1387,13 +1553,15 @@ int iterate_graph(hpf_handle *h, int n_iters)
   for (int t = 0; t < n_iters; ++t) {
     const uint32_t slot = h->ev_count % hpf_handle::RING;
     h->ev = h->evr[slot];
-    h->ring_graphed[slot] = true; h->ring_overlapped[slot] = false;
+    h->ring_graphed[slot] = true;
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
     h->u.l_stale = h->u.es_stale = h->it.l_stale = h->it.es_stale = true;
+    h->u.w_from_sweep = h->it.w_from_sweep = true; h->u.shadow_stale = h->it.shadow_stale = false;
     h->ev_count++;
     h->iterations++;
+    h->iters_counted++;
   }
   return HPF_OK;
 }
@@ -1503,7 +1671,10 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
       // K = 50: 3 instead of 4 -- measured on a C5 shard: 65.6 -> 51.7 ms); 2 asks for f48; 3 keeps
       // plain rows.  HPF_W_PACK=1 (experimental) packs whenever a shape exists.
       const bool force_pack = knob("HPF_W_PACK") && atoi(knob("HPF_W_PACK")) == 1;
-      const int want = cfg->w_storage == 2 ? WL_F48 : (cfg->w_storage == 0 || force_pack) && cfg->w_storage != 1 && cfg->w_storage != 3 ? WL_P59 : WL_PLAIN;
+      // w_storage 3 asks for plain doubles: where the default would pack, the rows keep the packed SHAPE (lanes per nonzero,
+      // columns, row stride of S) and hold plain doubles in its pieces (WL_F64) -- the layout a packed handle falls back to
+      // when a state turns up that p59 cannot hold, so that the two give the same bits
+      const int want = cfg->w_storage == 2 ? WL_F48 : (cfg->w_storage == 0 || cfg->w_storage == 3 || force_pack) && cfg->w_storage != 1 ? WL_P59 : WL_PLAIN;
       if (want != WL_PLAIN && !(phi_cfg_forced && want == WL_P59)) {
         long bestb = -1; int bg = 0, bl = 0;
         const int Gq[5] = {8, 16, 32, 64, 4};
@@ -1518,11 +1689,13 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
         const long plain_lines = ((long)h->ld * 8 + 127) / 128, packed_lines = (bestb + 127) / 128;
         bool take = bestb > 0 && (want == WL_F48 || force_pack || packed_lines < plain_lines);
         if (want == WL_F48 && bestb < 0) return fail(HPF_ERR_UNSUPPORTED);
-        // the sweep must have a shape for the packed stride too (G' * R' >= ld, R' <= 8, 16 at G' = 64)
+        // the sweep must have a shape for the packed stride too
         if (take) {
-          const uint32_t pld = (uint32_t)(bg * (want == WL_F48 ? (8 * bl) / 3 : (128 * bl) / 59));
+          const int e = want == WL_F48 ? (8 * bl) / 3 : (128 * bl) / 59;
+          const uint32_t pld = (uint32_t)(bg * e);
           bool fits = false;
-          for (int g : {64, 32, 16, 8, 4}) { const uint32_t r = (pld + (uint32_t)g - 1) / (uint32_t)g; fits |= r >= 1 && r <= (g == 64 ? 16u : 8u); }
+          if (want == WL_F48) for (int g : {64, 32, 16, 8, 4}) { const uint32_t r = (pld + (uint32_t)g - 1) / (uint32_t)g; fits |= r >= 1 && r <= (g == 64 ? 16u : 8u); }
+          else fits = bg <= 32 || e <= 16;      // p59: groups of twice the pass's lanes (<= 9 slots), or 64 lanes with a slot per element
           if (!fits && want == WL_F48) return fail(HPF_ERR_UNSUPPORTED);
           if (!fits) take = false;                         // e.g. 961..1024 columns: 1088 packed columns have none; rows stay plain
         }
@@ -1533,31 +1706,44 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
           h->pk.G = (uint32_t)bg; h->pk.L = (uint32_t)bl; h->pk.E = (uint32_t)e; h->pk.row_bytes = (uint32_t)(bg * bl) * 16u;
           h->pk.lgG = 0; while ((1u << h->pk.lgG) < (uint32_t)bg) ++h->pk.lgG;
           h->ld = (uint32_t)(bg * e);
+          if (want == WL_P59) {
+            const uint32_t ls = ((uint32_t)e + 1u) / 2u;
+            h->pks = h->pk; h->pks.L = ls; h->pks.E = 2u * ls; h->pks.row_bytes = (uint32_t)bg * ls * 16u;
+            if (cfg->w_storage == 3) { h->wl = WL_F64; h->pk = h->pks; h->phiR = (int)ls; }
+          }
         }
       }
     }
-    // the row sweep gives G' lanes to a row with R' columns each, G'*R' == ld exactly
-    // (48-bit W: G'*R' >= ld, the excess columns of the last slots are masked)
+    // The row sweep gives G' lanes to a row with R' columns each.  Plain rows: G'*R' == ld exactly.  p59 rows (and the plain
+    // doubles in their shape): G' is TWICE the pass's lanes -- the two lanes that share a packed lane swap their halves and
+    // build the row in registers (row_sweep_kernel, SW_REG_P59) -- or the pass's 64.  48-bit rows: G'*R' >= ld, built in LDS.
     h->swG = h->swR = 0;
-    const int Gs[5] = {64, 32, 16, 8, 4};
-    int best = 1 << 30;
-    for (int g : Gs) {
-      if (h->wl == WL_PLAIN && h->ld % (uint32_t)g) continue;
-      const int r = (int)((h->ld + (uint32_t)g - 1) / (uint32_t)g);
-      if (r < 1 || r > (g == 64 ? 16 : 8)) continue;
-      const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (g * 8 < 128 ? 1 : 0);   // same preferences as round 1's K sweep
-      if (p < best || (p == best && g < h->swG)) { best = p; h->swG = g; h->swR = r; }
-    }
-    if (!h->swG) return fail(HPF_ERR_UNSUPPORTED);
-    if (const char *e = knob("HPF_SWEEP_CFG")) {         // "G,R" with G*R == ld
-      int g = 0, r = 0;
-      if (sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= (g == 64 ? 16 : 8) && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
-          (uint32_t)(g * r) == h->ld) { h->swG = g; h->swR = r; }
+    if (h->wl == WL_P59 || h->wl == WL_F64) {
+      const uint32_t ep = h->ld / (uint32_t)h->phiG;                 // elements per lane of the p59 shape
+      if (h->phiG <= 32) { h->swG = 2 * h->phiG; h->swR = (int)((ep + 1) / 2); h->sw_mode = h->wl == WL_P59 ? SW_REG_P59 : SW_F64; }
+      else { h->swG = 64; h->swR = (int)ep; h->sw_mode = h->wl == WL_P59 ? SW_LDS_P59 : SW_F64; }
+    } else {
+      h->sw_mode = h->wl == WL_F48 ? SW_LDS_F48 : SW_PLAIN;
+      const int Gs[5] = {64, 32, 16, 8, 4};
+      int best = 1 << 30;
+      for (int g : Gs) {
+        if (h->wl == WL_PLAIN && h->ld % (uint32_t)g) continue;
+        const int r = (int)((h->ld + (uint32_t)g - 1) / (uint32_t)g);
+        if (r < 1 || r > (g == 64 ? 16 : 8)) continue;
+        const int p = (r == 1 ? 3 : 0) + (r > 7 ? 2 : 0) + (g * 8 < 128 ? 1 : 0);   // same preferences as round 1's K sweep
+        if (p < best || (p == best && g < h->swG)) { best = p; h->swG = g; h->swR = r; }
+      }
+      if (!h->swG) return fail(HPF_ERR_UNSUPPORTED);
+      if (const char *e = knob("HPF_SWEEP_CFG")) {         // "G,R" with G*R == ld (plain rows)
+        int g = 0, r = 0;
+        if (h->wl == WL_PLAIN && sscanf(e, "%d,%d", &g, &r) == 2 && r >= 1 && r <= (g == 64 ? 16 : 8) && (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) &&
+            (uint32_t)(g * r) == h->ld) { h->swG = g; h->swR = r; }
+      }
     }
   }
   if (const char *e = knob("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
   if (const char *e = knob("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
-  if (const char *e = knob("HPF_OVERLAP")) h->overlap_sweep = atoi(e) != 0;
+  if (const char *e = knob("HPF_SHADOW")) h->use_shadow = atoi(e) != 0;
   if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = knob("HPF_TILE")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_mode = v; }
@@ -1586,7 +1772,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     if (s == &h->u) { if ((rc = dalloc(h, &s->S, ne))) return fail(rc); }
     if ((rc = dalloc(h, &s->E, ne))) return fail(rc);
     if ((rc = dalloc(h, &s->L, ne))) return fail(rc);
-    { double *w = nullptr; if ((rc = dalloc(h, &w, ne))) return fail(rc); s->W = w; }   // sized for doubles; floats use half
+    { unsigned char *w = nullptr; if ((rc = dalloc(h, &w, w_bytes(h, s->rows)))) return fail(rc); s->W = w; }
     if ((rc = dalloc(h, &s->prior_E, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_used, s->rows))) return fail(rc);
     if ((rc = dalloc(h, &s->prior_rate, s->rows))) return fail(rc);
@@ -1607,7 +1793,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
     double lf[256]; lf[0] = std::log(1.0); lf[1] = lf[0];
     for (uint32_t y = 2; y < 256; ++y) lf[y] = lf[y - 1] + std::log((double)y);
     if ((rc = dalloc(h, &h->logfact, 256))) return fail(rc);
-    if ((rc = dalloc(h, &h->flags, 1))) return fail(rc);
+    if ((rc = dalloc(h, &h->flags, 4))) return fail(rc);
     if (hipMemcpyAsync(h->logfact, lf, sizeof lf, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(HPF_ERR_HIP);
@@ -1626,12 +1812,6 @@ void hpf_destroy(hpf_handle *h)
     (void)hipEventDestroy(h->ev_ready); (void)hipEventDestroy(h->ev_reduced);
     (void)hipStreamDestroy(h->comm_stream);
   }
-  if (h->side_stream) {
-    (void)hipStreamSynchronize(h->side_stream);
-    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->side_stream);
-  }
-  dfree(h->u_W_spare);
   double *ucol = h->u.colsum;  (void)ucol;      // lives inside exch
   h->u.colsum = nullptr;
   double *icol = h->it.colsum; h->it.colsum = nullptr;
@@ -1781,12 +1961,9 @@ static int finish_upload(hpf_handle *h, uint64_t nnz)
   if ((uint64_t)last != nnz) { h->err = "internal: item-major view lost nonzeros"; return HPF_ERR_HIP; }
   if ((rc = device_side_work(h, h->u, h->rowptr_dev, n))) return rc;
   if ((rc = device_side_work(h, h->it, h->colptr_dev, m))) return rc;
-  {
-    const size_t rowb = h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : (size_t)h->ld * (h->w32 ? 4 : 8);
-    if ((rc = build_tiled_side(h, h->u, h->rowptr_dev, m, nnz, rowb))) return rc;     // the user pass gathers item rows
-    if ((rc = build_tiled_side(h, h->it, h->colptr_dev, n, nnz, rowb))) return rc;
-  }
-  HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
+  if ((rc = build_work_lists_tiled(h, nnz))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, 8, h->stream));
+  h->iters_counted = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->nnz = nnz; h->have_csr = true;
   return HPF_OK;
@@ -1907,7 +2084,9 @@ static int set_state_impl(hpf_handle *h, hpf_state which, const double *host, si
   auto put2d = [&](double *dev, uint32_t c0) -> int {
     return on_device ? copy_in_dev(h, dev, h->ld, c0, host, rows, cols) : copy_in(h, dev, h->ld, c0, host, rows, cols);
   };
-  // a new state supersedes whatever the kernels flagged about the old one
+  // a new state supersedes whatever the kernels flagged about the old one -- but iterations a flushed entry made the
+  // passes skip are part of the old one: they are run first (recover_flush)
+  if ((rc = recover_if_flushed(h))) return rc;
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
   if (obj == 2 || obj == 3) {                 // xi / eta vectors
     if (count != rows) return HPF_ERR_INVALID;
@@ -2043,7 +2222,7 @@ int hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t cou
 // ---- snapshot: the loop's device state, verbatim -------------------------------
 namespace {
 struct SnapHeader {
-  char magic[8];                        // "HPFSNAP2"
+  char magic[8];                        // "HPFSNAP3"
   uint32_t n_users, n_items, K, ld, hier, bias, w32, iterations;
   // what else the state is only meaningful with: the priors, the job's shape and
   // the ratings it was fitted to -- a snapshot of another data set of the same dimensions,
@@ -2066,7 +2245,8 @@ void snapshot_sections(hpf_handle *h, const uint64_t rate_cnt[2], const uint32_t
   for (int k = 0; k < 2; ++k) {
     Side &s = *sides[k];
     const size_t mat = (size_t)s.rows * h->ld * 8, vec = (size_t)s.rows * 8, row = (size_t)h->ld * 8;
-    for (void *p : {(void *)s.S, (void *)s.E, (void *)s.L, s.W}) out->push_back({p, mat});
+    for (void *p : {(void *)s.S, (void *)s.E, (void *)s.L}) out->push_back({p, mat});
+    out->push_back({s.W, w_bytes(h, s.rows)});
     for (double *p : {s.prior_E, s.prior_used, s.prior_rate, s.prior_elog, s.prior_elog_used}) out->push_back({p, vec});
     out->push_back({s.colsum, row}); out->push_back({s.colsum_used, row});
     if (flags[k] & 64u) out->push_back({s.rate_set, (size_t)rate_cnt[k] * 8});
@@ -2076,12 +2256,13 @@ void snapshot_sections(hpf_handle *h, const uint64_t rate_cnt[2], const uint32_t
 uint32_t side_flag_word(const Side &s)
 {
   return (s.have_E ? 1u : 0u) | (s.have_L ? 2u : 0u) | (s.have_prior ? 4u : 0u) | (s.w_dirty ? 8u : 0u) |
-         (s.l_stale ? 16u : 0u) | (s.es_stale ? 32u : 0u) | (s.rate_set ? 64u : 0u) | (s.prior_shape_set ? 128u : 0u);
+         (s.l_stale ? 16u : 0u) | (s.es_stale ? 32u : 0u) | (s.rate_set ? 64u : 0u) | (s.prior_shape_set ? 128u : 0u) |
+         (s.w_from_sweep ? 256u : 0u);
 }
 void fill_snap_header(hpf_handle *h, SnapHeader *hd)
 {
   memset(hd, 0, sizeof *hd);
-  memcpy(hd->magic, "HPFSNAP2", 8);
+  memcpy(hd->magic, "HPFSNAP3", 8);
   hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
   hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->cfg.w_storage | ((uint32_t)h->wl << 8); hd->iterations = h->iterations;   // storage mode and the row layout in use
   hd->n_users_total = h->cfg.n_users_total; hd->rank = h->cfg.rank; hd->n_ranks = h->cfg.n_ranks;
@@ -2132,7 +2313,12 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
   if (h->phase != 0 || h->items_reduce_pending) { h->err = "snapshot load inside an iteration"; return HPF_ERR_STATE; }
   // ---- everything is validated before the handle is touched: a rejected blob leaves it as it was
   SnapHeader hd; memcpy(&hd, host, sizeof hd);
-  if (memcmp(hd.magic, "HPFSNAP2", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
+  // a snapshot taken after the rows fell back to plain doubles loads into a handle that still packs them: same job, the
+  // handle follows (validated below like everything else, but the layout has to be known to size the sections)
+  const bool follow = !memcmp(hd.magic, "HPFSNAP3", 8) && h->wl == WL_P59 && hd.w32 == (h->cfg.w_storage | ((uint32_t)WL_F64 << 8)) &&
+                      hd.n_users == h->u.rows && hd.n_items == h->it.rows && hd.K == h->K && hd.ld == h->ld && hd.total_bytes == bytes;
+  if (follow) { int rc0 = recover_if_flushed(h); if (!rc0 && h->wl == WL_P59) rc0 = set_rows_f64(h); if (rc0) return rc0; h->fallbacks++; }
+  if (memcmp(hd.magic, "HPFSNAP3", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
       hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (h->cfg.w_storage | ((uint32_t)h->wl << 8))) {
     h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
   }
@@ -2153,7 +2339,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     size_t tot = sizeof hd;
     for (int k = 0; k < 2; ++k) {
       const size_t mat = (size_t)sides[k]->rows * h->ld * 8, vec = (size_t)sides[k]->rows * 8, row = (size_t)h->ld * 8;
-      tot += 4 * mat + 5 * vec + 2 * row;
+      tot += 3 * mat + w_bytes(h, sides[k]->rows) + 5 * vec + 2 * row;
       if (hd.side_flags[k] & 64u) tot += (size_t)hd.rate_set_count[k] * 8;
       if (hd.side_flags[k] & 128u) tot += vec;
     }
@@ -2184,12 +2370,16 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
   for (int k = 0; k < 2; ++k) {
     Side &s = *sides[k]; const uint32_t f = hd.side_flags[k];
     s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
+    s.w_from_sweep = (f & 256u) != 0;
+    s.shadow_stale = s.W_shadow != nullptr && !s.w_dirty;       // the snapshot carries W alone
+    if (s.shadow_stale) h->derived_dirty = true;
   }
-  h->derived_dirty = hd.derived_dirty != 0;
-  h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
+  h->start_sums_done = hd.derived_dirty == 0;  // the tail of the exchange buffer came with the snapshot
+  h->derived_dirty = hd.derived_dirty != 0 || h->derived_dirty;
   h->iterations = hd.iterations;
   h->phase = 0;
-  HIPCHK(h, hipMemsetAsync(h->flags, 0, 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->flags, 0, 8, h->stream));
+  h->iters_counted = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return HPF_OK;
 }
@@ -2213,7 +2403,6 @@ int hpf_iterate(hpf_handle *h, int n_iters)
   if (n_iters > 0 && want_graph(h)) return iterate_graph(h, n_iters);
   for (int t = 0; t < n_iters; ++t) {
     int rc;
-    if (h->overlap_sweep) { if ((rc = iterate_overlapped(h))) return rc; continue; }
     if ((rc = iterate_local(h))) return rc;
     if ((rc = iterate_global(h))) return rc;
   }
@@ -2495,6 +2684,9 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->tiles_user = h->u.tiles; out->tiles_item = h->it.tiles;
   out->tile_rows_user = h->u.tile_rows; out->tile_rows_item = h->it.tile_rows;
   out->heavy_min_nnz_user = h->u.tiles ? h->u.light_below : 0; out->heavy_min_nnz_item = h->it.tiles ? h->it.light_below : 0;
+  out->w_fallbacks = h->fallbacks;
+  out->w_shadow_user = h->u.W_shadow ? 1u : 0u; out->w_shadow_item = h->it.W_shadow ? 1u : 0u;
+  out->notes = h->notes;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
 }
@@ -2504,13 +2696,15 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if (!h || !ms_out || reps < 1 || (side != 0 && side != 1)) return HPF_ERR_INVALID;
   if (!h->have_csr) { h->err = "hpf_upload_csr has not been called"; return HPF_ERR_STATE; }
   if (h->w32 || (h->wl == WL_PLAIN && h->phiV != 2)) { h->err = "gather-only probe: rows of 16-byte pieces only"; return HPF_ERR_UNSUPPORTED; }
+  { int rc0 = recover_if_flushed(h); if (rc0) return rc0; }
   int rc;
   if ((rc = prepare_derived(h))) return rc;
   Side &own = side ? h->it : h->u, &oth = side ? h->u : h->it;
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = nullptr; a.partial = nullptr; a.flags = h->flags;
-  a.chunks = own.chunks;
+  a.chunks = own.chunks; a.W_oth_tiled = oth.W_shadow; a.ld = h->ld;
+  const bool mixed = pass_is_mixed(h, own, oth);
   *ms_out = 0.0f;
   if (!a.nseg) return HPF_OK;
   uint32_t *sink = nullptr;
@@ -2519,10 +2713,10 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);      // warm-up
+  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, mixed, a, sink, blocks, h->stream);      // warm-up
   if (ok) {
     e = hipEventRecord(e0, h->stream);
-    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);
+    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, mixed, a, sink, blocks, h->stream);
     if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -2557,15 +2751,7 @@ int hpf_mean_timing(hpf_handle *h, uint32_t n_last, hpf_timing *out)
     hipEvent_t *ev = h->evr[slot];
     float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // a graph-replayed iteration is one launch: only its total is known
-    if (h->ring_overlapped[slot] && !h->ring_graphed[slot]) {
-      // user pass first; the user sweep ran on the side stream while the item pass ran on the main one
-      HIPCHK(h, hipEventElapsedTime(&ms[2], ev[0], ev[3]));      // user pass
-      HIPCHK(h, hipEventElapsedTime(&ms[3], ev[3], ev[4]));      // its combine
-      HIPCHK(h, hipEventElapsedTime(&ms[0], ev[4], ev[1]));      // item pass (the user sweep beside it)
-      HIPCHK(h, hipEventElapsedTime(&ms[1], ev[1], ev[2]));      // its combine
-      HIPCHK(h, hipEventElapsedTime(&ms[4], ev[4], ev[5]));      // user sweep, start of the fork -> its last kernel
-      HIPCHK(h, hipEventElapsedTime(&ms[5], ev[7], ev[6]));      // item sweep
-    } else if (!h->ring_graphed[slot]) {
+    if (!h->ring_graphed[slot]) {
       for (int j = 0; j < 5; ++j) HIPCHK(h, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
       HIPCHK(h, hipEventElapsedTime(&ms[7], ev[5], ev[7]));      // exchange the stream waited for
       HIPCHK(h, hipEventElapsedTime(&ms[5], ev[7], ev[6]));      // the item sweep itself
@@ -2638,7 +2824,7 @@ int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item,
   // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
   const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
   const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
-  const uint64_t seb = h->w32 ? 32 : h->wl == WL_F48 ? 48 : h->wl == WL_P59 ? 59 : 64, sa = 8;   // BITS per stored W element; bytes per accumulator
+  const uint64_t seb = h->w32 ? 32 : h->wl == WL_F48 ? 48 : h->wl == WL_P59 ? 59 : 64, sa = 8;   // (the fp64 shadow of the tiled share: still 59 -- what HAS to move)   // BITS per stored W element; bytes per accumulator
   if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * seb / 8 + n * Kp * seb / 8 + n * Kp * sa;
   if (phi_item) *phi_item = nnz * Kp * seb / 8;
   if (rows) *rows = (n + m) * Kp * 2 * sa + (n + m) * Kp * 2 * seb / 8 + 64 * (n + m);

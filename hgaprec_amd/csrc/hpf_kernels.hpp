@@ -20,6 +20,8 @@
 
 namespace hpf {
 
+constexpr int HPF_COMBINE_MAXCOLS = 1152;     // widest row stride: 64 lanes x 17 (or 18) elements
+
 // ---------------------------------------------------------------------
 // work item of a phi pass: up to seg_max consecutive nonzeros of ONE owner row
 // ---------------------------------------------------------------------
@@ -119,12 +121,34 @@ struct PhiArgs {
   const void     *W_oth;    // [rows_oth x G*R*V] of WT
   double         *S_own;    // [rows_own x G*R*V]  raw sums (prior added by sweep)
   double         *partial;  // [npartial x G*R*V]
-  uint32_t       *flags;    // bit 0 set when a live nonzero saw sum_k e_k == 0 (underflow of W)
-  // tiled pass (hpf_build.hpp): workgroup b works on the segments [chunks[b].x, chunks[b].y), one wave
+  uint32_t       *flags;    // [0] bit 0: a live nonzero saw sum_k e_k == 0 (underflow of W); bit 1: a sweep had to flush an
+                            // entry the p59 rows cannot hold; bit 2: a pass has seen bit 1 -- everything launched since is a
+                            // no-op until the host has switched the row layout (hpf_capi.hip, recover_flush)
+                            // [1] iterations begun with bits 1 and 2 clear (counted by the item-major pass, which opens an iteration)
+  // tiled pass (hpf_build.hpp): workgroup b works on the segments [chunks[b].x, chunks[b].y & 0x7fffffff), one wave
   // per segment in turn; the host lays the chunks out so that b % 8 -- the XCD a workgroup lands on --
-  // walks one tile after another.  NULL: the waves stride over the whole list.
+  // walks one tile after another.  NULL: the waves stride over the whole list.  Bit 31 of chunks[b].y marks a chunk
+  // of TILED segments (runs inside one tile of the gathered matrix): phi_pass_mixed_kernel gathers those from
+  // W_oth_tiled, the plain-fp64 copy of the gathered rows -- they come out of the XCD's L2, where instructions,
+  // not bytes, are what a gather costs -- and everything else from the packed rows W_oth.
   const uint2    *chunks;
+  const void     *W_oth_tiled;
+  uint32_t        ld;       // row stride of S_own / partial, columns (layouts whose rows do not fix it: codec_f64)
 };
+
+// Entry of every phi-pass kernel.  A sweep that could not store an element in the packed rows raises bit 1;
+// the passes that follow must not run on that W: they return at once (and the item-major pass, which opens
+// an iteration, turns bit 1 into bit 2, which stops the sweeps as well) until the host -- at its next
+// synchronisation point -- has moved the handle to plain fp64 rows and repeats what was skipped.
+__device__ __forceinline__ bool phi_pass_skips(const PhiArgs &a, int side)
+{
+  const uint32_t fl = a.flags[0];
+  if (side == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (fl & 2u) atomicOr(a.flags, 4u);
+    else if (!(fl & 4u)) atomicAdd(a.flags + 1, 1u);
+  }
+  return (fl & 6u) != 0u;
+}
 
 // the segments of this wave: first, end, stride
 struct SegRange { uint32_t s, end, step; };
@@ -134,7 +158,7 @@ __device__ __forceinline__ SegRange seg_range(const PhiArgs &a)
   if (a.chunks) {
     const uint2 c = a.chunks[blockIdx.x];
     r.s = __builtin_amdgcn_readfirstlane(c.x + (threadIdx.x >> 6));
-    r.end = __builtin_amdgcn_readfirstlane(c.y);
+    r.end = __builtin_amdgcn_readfirstlane(c.y & 0x7fffffffu);
     r.step = blockDim.x >> 6;
   } else {
     r.s = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -143,6 +167,9 @@ __device__ __forceinline__ SegRange seg_range(const PhiArgs &a)
   }
   return r;
 }
+
+// an item-major pass over no nonzeros at all still opens the iteration (phi_pass_skips)
+__global__ void phi_open_kernel(PhiArgs a) { (void)phi_pass_skips(a, 1); }
 
 // one batch: x = the gathered rows (one nonzero per group), yf = its rating
 // factor as a float (0 for an empty slot)
@@ -178,6 +205,7 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
   const int lane = threadIdx.x & 63;
   const int g = lane % G;                // column lane
   const int q = lane / G;                // group = nonzero slot in a batch
+  if (phi_pass_skips(a, SIDE)) return;
   const SegRange sr = seg_range(a);
   const WT *W_own = (const WT *)a.W_own + (size_t)g * V;
   const WT *W_oth = (const WT *)a.W_oth + (size_t)g * V;
@@ -302,9 +330,23 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 // Row stride of the fp64 matrices (S, E, Elog) and of the exchange buffer: ld = G*E columns.
 // Arithmetic and accumulators are fp64 in every mode.
 // ---------------------------------------------------------------------
-enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3 };      // layout codes (hpf_work_info.w_layout)
+//   f64  plain fp64 elements in the same interleaved pieces, two per piece (E = 2L).  What a handle falls back to
+//        when a state turns up that p59 cannot hold (hpf_capi.hip, recover_flush), what hpf_config.w_storage = 3
+//        asks for from the start, and the layout of the SHADOW copy the tiled share of a pass gathers from.
+//        The row stride of S / partial stays that of the packed shape it stands in for (PhiArgs::ld <= G * E).
+enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3, WL_F64 = 4 };      // layout codes (hpf_work_info.w_layout)
+
+template <int L> struct codec_f64 {
+  static constexpr int E = 2 * L;
+  static constexpr bool fixed_ld = false;
+  static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
+  {
+    return __hiloint2double((int)d[2 * e + 1], (int)d[2 * e]);
+  }
+};
 
 template <int L> struct codec_f48 {
+  static constexpr bool fixed_ld = true;
   static constexpr int E = (8 * L) / 3;                   // 2 5 8 10 13 16 18 21
   static_assert(E + (E + 1) / 2 <= 4 * L, "lane dwords overflow");
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
@@ -315,6 +357,7 @@ template <int L> struct codec_f48 {
 };
 
 template <int L> struct codec_p59 {
+  static constexpr bool fixed_ld = true;
   static constexpr int E = (128 * L) / 59;                // 2 4 6 8 10 13 15 17
   static_assert(E + (27 * E + 31) / 32 <= 4 * L, "lane dwords overflow");
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
@@ -386,14 +429,22 @@ __device__ __forceinline__ void packed_copy_out(const uint32_t *buf, void *W, si
   for (uint32_t p = li; p < pk.row_bytes / 16; p += nl) dst[p] = src[p];
 }
 
-template <class Codec, int G, int L>
-__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * L], const double (&own)[Codec::E],
-                                                 double (&acc)[Codec::E], float yf, bool &underflow)
+// one batch over E element slots: x = the gathered rows in OthC's layout (LT pieces per lane)
+// element c of a row of plain doubles in interleaved pieces (codec_f64): piece e/2 of lane g, half e%2
+__device__ __forceinline__ void f64_put(void *W, size_t row, const PackedRow &pk, uint32_t c, double w)
 {
-  constexpr int E = Codec::E;
+  const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
+  double *d = reinterpret_cast<double *>((unsigned char *)W + row * (size_t)pk.row_bytes);
+  d[((((e >> 1) << pk.lgG) + g) << 1) + (e & 1u)] = w;
+}
+
+template <class OthC, int E, int G, int LT>
+__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[E],
+                                                 double (&acc)[E], float yf, bool &underflow)
+{
   double xv[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) xv[e] = Codec::get(x, e);
+  for (int e = 0; e < E; ++e) xv[e] = OthC::get(x, e);
   double s[2] = {0.0, 0.0};
 #pragma unroll
   for (int e = 0; e < E; ++e) s[e & 1] = (e < 2) ? own[e] * xv[e] : fma(own[e], xv[e], s[e & 1]);
@@ -406,24 +457,30 @@ __device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * L], con
   for (int e = 0; e < E; ++e) acc[e] = fma(xv[e], scale, acc[e]);
 }
 
-template <template <int> class CodecT, int G, int L, int SIDE>
-__global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
+// The segments of one wave, over rows of 16-byte pieces: the owner's row in OwnC's layout (LO pieces per
+// lane), the gathered rows in OthC's (LT pieces).  E = OwnC::E element slots are worked on (OthC::E >= E:
+// a shadow row may carry one padding slot more).  W_own / W_oth already point at this lane's first piece.
+template <class OwnC, class OthC, int G, int LO, int LT>
+__device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &sr, const unsigned char *W_own,
+                                             const unsigned char *W_oth, int lane, bool &underflow)
 {
-  using Codec = CodecT<L>;
   constexpr int NG = 64 / G;
-  constexpr int E = Codec::E;
-  constexpr uint32_t LD = G * E;                 // columns: stride of S / partial
-  constexpr uint32_t ROWB = G * L * 16;          // bytes of a W row
-  const int lane = threadIdx.x & 63;
+  constexpr int E = OwnC::E;
+  static_assert(OthC::E >= E, "the gathered layout must cover the owner's element slots");
+  const uint32_t LD = OwnC::fixed_ld ? (uint32_t)(G * E) : a.ld;       // columns: stride of S / partial
+  constexpr uint32_t ROWO = G * LO * 16, ROWT = G * LT * 16;           // bytes of a row of W, either layout
   const int g = lane % G, q = lane / G;
-  const SegRange sr = seg_range(a);
-  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
-  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
-  bool underflow = false;
 
-  auto load_row = [&](uint32_t (&d)[4 * L], const unsigned char *base) {
+  auto load_own = [&](uint32_t (&d)[4 * LO], const unsigned char *base) {
 #pragma unroll
-    for (int t = 0; t < L; ++t) {
+    for (int t = 0; t < LO; ++t) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
+      d[4 * t] = v.x; d[4 * t + 1] = v.y; d[4 * t + 2] = v.z; d[4 * t + 3] = v.w;
+    }
+  };
+  auto load_row = [&](uint32_t (&d)[4 * LT], const unsigned char *base) {
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
       const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
       d[4 * t] = v.x; d[4 * t + 1] = v.y; d[4 * t + 2] = v.z; d[4 * t + 3] = v.w;
     }
@@ -455,13 +512,13 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
     uint32_t cur_i = nxt_i;
     float cur_y = nxt_y;
     const uint32_t nb = (len + NG - 1) / NG;
-    uint32_t xa[4 * L], xb[4 * L];
+    uint32_t xa[4 * LT], xb[4 * LT];
     float ya = 0.0f, yb = 0.0f;
-    auto gather = [&](uint32_t (&x)[4 * L], float &y, uint32_t b) {
+    auto gather = [&](uint32_t (&x)[4 * LT], float &y, uint32_t b) {
       const int src = (int)((b % G) * NG) + q;
       const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
       y = __shfl(cur_y, src, 64);
-      load_row(x, W_oth + (size_t)in * ROWB);
+      load_row(x, W_oth + (size_t)in * ROWT);
     };
     // chunk c has become the current one: fetch the one after it -- of this segment, or the
     // first one of the next segment
@@ -478,27 +535,27 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
     };
     double own[E], acc[E];
     {
-      uint32_t r[4 * L];
-      load_row(r, W_own + (size_t)sg.row * ROWB);
+      uint32_t r[4 * LO];
+      load_own(r, W_own + (size_t)sg.row * ROWO);
       gather(xa, ya, 0);          // unconditional (a conditional gather costs copies and waits): past the
       gather(xb, yb, 1);          // segment's end the index reads 0 -- row 0, loaded and never used
       fetch_after(0);
 #pragma unroll
-      for (int e = 0; e < E; ++e) { own[e] = Codec::get(r, e); acc[e] = 0.0; }
+      for (int e = 0; e < E; ++e) { own[e] = OwnC::get(r, e); acc[e] = 0.0; }
     }
     if (len > 0) {
       // same schedule as phi_pass_kernel: two register sets, peeled tail
       uint32_t bb = 0;
       for (; bb + 3 < nb; bb += 2) {
-        phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
         __builtin_amdgcn_sched_barrier(0);
         if (((bb + 2) % G) == 0) next_chunk(bb + 2);
         gather(xa, ya, bb + 2);
-        phi_batch_packed<Codec, G, L>(xb, own, acc, yb, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
         __builtin_amdgcn_sched_barrier(0);
         gather(xb, yb, bb + 3);
       }
-      phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
+      phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
       if (bb + 1 < nb) {
         const bool third = bb + 2 < nb;
         __builtin_amdgcn_sched_barrier(0);
@@ -506,8 +563,8 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
           if (((bb + 2) % G) == 0) next_chunk(bb + 2);
           gather(xa, ya, bb + 2);
         }
-        phi_batch_packed<Codec, G, L>(xb, own, acc, yb, underflow);
-        if (third) phi_batch_packed<Codec, G, L>(xa, own, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
+        if (third) phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
       }
     }
     double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + g;
@@ -518,9 +575,44 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
       if (G <= 16) r += __shfl_xor(r, 16, 64);
       if (G <= 8)  r += __shfl_xor(r, 8, 64);
       if (G <= 4)  r += __shfl_xor(r, 4, 64);
-      if (q == 0) dst[(size_t)e * G] = own[e] * r;
+      if (q == 0 && (OwnC::fixed_ld || (uint32_t)(e * G + g) < LD)) dst[(size_t)e * G] = own[e] * r;
     }
   }
+}
+
+template <template <int> class CodecT, int G, int L, int SIDE>
+__global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
+{
+  if (phi_pass_skips(a, SIDE)) return;
+  const int lane = threadIdx.x & 63;
+  const SegRange sr = seg_range(a);
+  bool underflow = false;
+  phi_segments<CodecT<L>, CodecT<L>, G, L, L>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
+                                              (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, underflow);
+  if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
+}
+
+// p59 rows; the chunks of TILED segments gather from the plain-fp64 shadow of the other side's rows (round 4).
+// A gather that hits the XCD's own L2 costs instructions, not bytes, and the 59-bit decode was 39 % of the
+// tiled share's VALU work: there the rows are read as plain doubles (7 lines instead of 6 at K = 100 -- out of
+// L2), everywhere else -- every gather that crosses the fabric -- in the packed form.  The branch is per
+// workgroup (a chunk holds one kind of segment); a tile is sized in bytes of the rows it is read from.
+template <int G, int L, int SIDE>
+__global__ __launch_bounds__(256, 3) void phi_pass_mixed_kernel(PhiArgs a)
+{
+  constexpr int LS = (codec_p59<L>::E + 1) / 2;
+  if (phi_pass_skips(a, SIDE)) return;
+  const int lane = threadIdx.x & 63;
+  const SegRange sr = seg_range(a);
+  const bool tiled = (a.chunks[blockIdx.x].y >> 31) != 0u;             // wave-uniform
+  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)(lane % G) * 16;
+  bool underflow = false;
+  if (tiled)
+    phi_segments<codec_p59<L>, codec_f64<LS>, G, L, LS>(a, sr, W_own, (const unsigned char *)a.W_oth_tiled + (size_t)(lane % G) * 16,
+                                                        lane, underflow);
+  else
+    phi_segments<codec_p59<L>, codec_p59<L>, G, L, L>(a, sr, W_own, (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16,
+                                                      lane, underflow);
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
@@ -532,28 +624,28 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
 // Rows of L 16-byte pieces per lane at stride G*16: the packed layouts and plain fp64 rows with
 // 16-byte loads (V = 2) alike.
 // ---------------------------------------------------------------------
-template <int G, int L>
-__global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *sink)
+template <int G, int LO, int LT>
+__device__ __forceinline__ void gather_only_segments(const PhiArgs &a, const SegRange &sr, const unsigned char *W_own,
+                                                     const unsigned char *W_oth, int lane, uint4 &acc)
 {
   constexpr int NG = 64 / G;
-  constexpr uint32_t ROWB = G * L * 16;
-  const int lane = threadIdx.x & 63;
-  const int g = lane % G, q = lane / G;
-  const SegRange sr = seg_range(a);
-  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)g * 16;
-  const unsigned char *W_oth = (const unsigned char *)a.W_oth + (size_t)g * 16;
-  uint4 acc = {0u, 0u, 0u, 0u};
-  auto load_row = [&](uint4 (&d)[L], const unsigned char *base) {
+  constexpr uint32_t ROWO = G * LO * 16, ROWT = G * LT * 16;
+  const int q = lane / G;
+  auto load_own = [&](uint4 (&d)[LO], const unsigned char *base) {
 #pragma unroll
-    for (int t = 0; t < L; ++t) d[t] = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
+    for (int t = 0; t < LO; ++t) d[t] = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
   };
-  auto fold = [&](const uint4 (&d)[L]) {
+  auto load_row = [&](uint4 (&d)[LT], const unsigned char *base) {
 #pragma unroll
-    for (int t = 0; t < L; ++t) { acc.x ^= d[t].x; acc.y ^= d[t].y; acc.z ^= d[t].z; acc.w ^= d[t].w; }
+    for (int t = 0; t < LT; ++t) d[t] = *reinterpret_cast<const uint4 *>(base + (size_t)t * G * 16);
+  };
+  auto fold = [&](const uint4 (&d)[LT]) {
+#pragma unroll
+    for (int t = 0; t < LT; ++t) { acc.x ^= d[t].x; acc.y ^= d[t].y; acc.z ^= d[t].z; acc.w ^= d[t].w; }
   };
   auto load_i = [&](int64_t start, uint32_t len, uint32_t o) -> uint32_t { return (o < len) ? a.idx[start + o] : 0u; };
   if (sr.s >= sr.end) return;
-  Seg sgn = a.segs[sr.s];                           // the pass's stream of segments (phi_pass_packed_kernel)
+  Seg sgn = a.segs[sr.s];                           // the pass's stream of segments (phi_segments)
   uint32_t nxt_i = load_i(sgn.start, sgn.len, (uint32_t)lane);
   for (uint32_t s = sr.s; s < sr.end; s += sr.step) {
     const Seg sg = sgn;
@@ -563,11 +655,11 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
     const int64_t start = sg.start;
     uint32_t cur_i = nxt_i;
     const uint32_t nb = (len + NG - 1) / NG;
-    uint4 xa[L], xb[L];
-    auto gather = [&](uint4 (&x)[L], uint32_t b) {
+    uint4 xa[LT], xb[LT];
+    auto gather = [&](uint4 (&x)[LT], uint32_t b) {
       const int src = (int)((b % G) * NG) + q;
       const uint32_t in = (uint32_t)__shfl((int)cur_i, src, 64);
-      load_row(x, W_oth + (size_t)in * ROWB);
+      load_row(x, W_oth + (size_t)in * ROWT);
     };
     auto fetch_after = [&](uint32_t c) {
       const uint32_t o = (c + 1) * 64u;
@@ -577,7 +669,12 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
       nxt_i = load_i(st, ln, of + lane);
     };
     auto next_chunk = [&](uint32_t b) { cur_i = nxt_i; fetch_after(b / G); };
-    { uint4 r[L]; load_row(r, W_own + (size_t)sg.row * ROWB); gather(xa, 0); gather(xb, 1); fetch_after(0); fold(r); }
+    {
+      uint4 r[LO];
+      load_own(r, W_own + (size_t)sg.row * ROWO); gather(xa, 0); gather(xb, 1); fetch_after(0);
+#pragma unroll
+      for (int t = 0; t < LO; ++t) { acc.x ^= r[t].x; acc.y ^= r[t].y; acc.z ^= r[t].z; acc.w ^= r[t].w; }
+    }
     if (len == 0) continue;
     uint32_t bb = 0;
     for (; bb + 3 < nb; bb += 2) {
@@ -601,6 +698,22 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
       if (third) fold(xa);
     }
   }
+}
+
+// LS > 0: the chunks of tiled segments gather rows of LS pieces from a.W_oth_tiled, like phi_pass_mixed_kernel
+template <int G, int L, int LS>
+__global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *sink)
+{
+  const int lane = threadIdx.x & 63;
+  const SegRange sr = seg_range(a);
+  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)(lane % G) * 16;
+  uint4 acc = {0u, 0u, 0u, 0u};
+  bool tiled = false;
+  if constexpr (LS > 0) tiled = a.chunks && (a.chunks[blockIdx.x].y >> 31) != 0u;
+  if constexpr (LS > 0) {
+    if (tiled) gather_only_segments<G, L, LS>(a, sr, W_own, (const unsigned char *)a.W_oth_tiled + (size_t)(lane % G) * 16, lane, acc);
+  }
+  if (!tiled) gather_only_segments<G, L, L>(a, sr, W_own, (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, acc);
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;      // keeps the loads alive
 }
 
@@ -609,32 +722,71 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
 // loop is unrolled 16-fold, so 32 independent loads are in flight per lane
 // (the longest row -- thousands of slots for a blockbuster item -- sets the
 // kernel's duration: it is a latency chain).  The adds stay in slot order.
-__global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
-                                                               const double *partial, double *S, uint32_t ld)
+__device__ __forceinline__ void combine_columns(const double *partial, uint32_t first_slot, uint32_t nslots, uint32_t ld,
+                                                int lane, double (&s0)[1], double (&s1)[1], uint32_t c)
 {
+  const bool two = c + 64 < ld;
+  const double *p0 = partial + (size_t)first_slot * ld + c;
+  const double *p1 = two ? p0 + 64 : p0;
+  double a0 = 0.0, a1 = 0.0;
+  uint32_t q = 0;
+  for (; q + 16 <= nslots; q += 16) {
+    double v0[16], v1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * ld]; v1[j] = p1[(size_t)(q + j) * ld]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a0 += v0[j]; a1 += v1[j]; }
+  }
+  for (; q < nslots; ++q) { a0 += p0[(size_t)q * ld]; a1 += p1[(size_t)q * ld]; }
+  s0[0] = a0; s1[0] = a1;
+}
+
+__global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
+                                                               const double *partial, double *S, uint32_t ld,
+                                                               const uint32_t *flags)
+{
+  if (flags[0] & 6u) return;                       // the pass before it did not run (phi_pass_skips)
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t r = wave; r < nrows; r += nwaves) {
     const LongRow lr = rows[r];
     for (uint32_t c = lane; c < ld; c += 128) {
-      const bool two = c + 64 < ld;
-      const double *p0 = partial + (size_t)lr.first_slot * ld + c;
-      const double *p1 = two ? p0 + 64 : p0;
-      double s0 = 0.0, s1 = 0.0;
-      uint32_t q = 0;
-      for (; q + 16 <= lr.nslots; q += 16) {
-        double v0[16], v1[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * ld]; v1[j] = p1[(size_t)(q + j) * ld]; }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { s0 += v0[j]; s1 += v1[j]; }
-      }
-      for (; q < lr.nslots; ++q) { s0 += p0[(size_t)q * ld]; s1 += p1[(size_t)q * ld]; }
+      double s0[1], s1[1];
+      combine_columns(partial, lr.first_slot, lr.nslots, ld, lane, s0, s1, c);
       double *d = S + (size_t)lr.row * ld + c;
-      d[0] = s0;
-      if (two) d[64] = s1;
+      d[0] = s0[0];
+      if (c + 64 < ld) d[64] = s1[0];
     }
+  }
+}
+
+// The same sum with a WORKGROUP per row (round 4): rows of a tiled side carry one partial per tile they meet
+// (C2's heavy items: 184, C4's: 176) and a single wave walking that chain is a latency chain of a dozen round
+// trips while most of the chip idles.  The four waves take a quarter of the slots each -- contiguous quarters,
+// cut by the slot count alone -- and the four sums are added in wave order: a fixed tree, the same bits on
+// every run (the order differs from the one-wave kernel's, which is why a side uses one of the two throughout).
+__global__ __launch_bounds__(256) void combine_partials_wg_kernel(const LongRow *rows, uint32_t nrows,
+                                                                  const double *partial, double *S, uint32_t ld,
+                                                                  const uint32_t *flags)
+{
+  if (flags[0] & 6u) return;
+  __shared__ double part[4][HPF_COMBINE_MAXCOLS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const LongRow lr = rows[r];
+    const uint32_t per = (lr.nslots + 3) / 4;
+    const uint32_t q0 = min(per * wv, lr.nslots), q1 = min(q0 + per, lr.nslots);
+    for (uint32_t c = lane; c < ld; c += 128) {
+      double s0[1], s1[1];
+      combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, lane, s0, s1, c);
+      part[wv][c] = s0[0];
+      if (c + 64 < ld) part[wv][c + 64] = s1[0];
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ld; c += 256)
+      S[(size_t)lr.row * ld + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+    __syncthreads();
   }
 }
 
@@ -741,16 +893,20 @@ __device__ __forceinline__ double digamma_pos(double x)
 // ---------------------------------------------------------------------
 struct SweepArgs {
   const double *S;          // [rows x ld] raw phi sums (read only)
-  void         *W;          // [rows x ld] double, or float when w32
+  void         *W;          // [rows x ld] double, or float when w32; packed / f64 rows: [rows x pk.row_bytes]
   uint32_t      w32;
   const double *prior_E;    // [rows] E[xi] / E[eta] the rate uses (hier); updated by prior_update_kernel
   double       *prior_rate; // [rows] out: rate of the xi/eta Gamma, r0 + sum_k E[row,k]
   double        psi_prior_shape; // psi(s0 + K*s0), constant, from the host (prior_update_kernel)
   const double *colsum_oth; // [ld]   sum over the other side's rows of E
+  double       *colsum_used;// [ld]   out: copy of colsum_oth -- what this rate was built from (export of *_rate.tsv,
+                            //        and what a W-only repeat of this sweep reads); NULL: no copy (the repeat itself)
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
-  PackedRow     pk;         // packed W rows (WL != WL_PLAIN): the phi kernel's G, E, L and the row bytes
-  uint32_t     *flags;      // bit 1: a nonzero W below 2^-126 was flushed by the p59 layout
+  PackedRow     pk;         // rows of W in 16-byte pieces (every mode but SW_PLAIN): the phi kernel's G, E, L and the row bytes
+  void         *W_shadow;   // plain-fp64 copy of the rows for the tiled share of the other side's pass, or NULL
+  PackedRow     pks;        // its shape
+  uint32_t     *flags;      // bit 1: a nonzero W below 2^-126 was flushed by the p59 layout; bit 2: do not run
   int32_t       bias_col;   // column holding this side's bias (-1: none)
   int32_t       junk_col;   // column holding the other side's bias (-1: none)
   double        bias_rate_add;  // n_other_total for the bias column
@@ -758,22 +914,60 @@ struct SweepArgs {
   uint32_t      hier;
 };
 
-// WL = WL_PLAIN: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no
-// column test.  Packed layouts (WL_P59, WL_F48): the stride a.ld = G_phi * E may be smaller than
-// G*R; the slots from tb on then also hold columns past the end of the row, whose loads and
-// stores are masked, and the group builds the packed row in LDS before it goes out.
-template <int G, int R, int WL>
+// how a sweep writes the rows of W
+enum { SW_PLAIN = 0,      // double (or float, a.w32) at stride G*R: no column test
+       SW_LDS_F48 = 2,    // the group builds the packed row in LDS (any G): the 48-bit layout ...
+       SW_LDS_P59 = 3,    // ... and p59 where the register form below has no shape (64-lane groups of the pass)
+       SW_F64 = 4,        // plain doubles into interleaved pieces (codec_f64): 8-byte stores, no staging
+       SW_REG_P59 = 5 };  // p59 built in REGISTERS (round 4): the sweep's group is twice the pass's
+
+// lane ^ GP for the power-of-two distances a sweep group spans
+template <int GP>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v)
+{
+  if (GP == 8)  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);      // row_ror:8
+  if (GP == 4)  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                        // xor 4 (bit mode)
+  if (GP == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                        // xor 16
+  return (uint32_t)__shfl_xor((int)v, GP, 64);
+}
+
+// the p59 shape a register-building sweep of R slots serves: the pass gives a nonzero GP = G/2 lanes with E elements
+// each, the sweep's lane (gp, h) owns the elements e = h + 2t.  E <= 10 is even (L <= 5), above that odd: R names it.
+template <int R> struct p59_of_slots {
+  static constexpr int E = R <= 5 ? 2 * R : 2 * R - 1;
+  static constexpr int L = (59 * E + 127) / 128;
+  static constexpr bool valid = R != 6 && R <= 9 && codec_p59<L>::E == E;
+};
+
+// element e of a lane's dwords D (p59): its low word, and its 27-bit field OR-ed into the stream.  Compile-time places.
+template <int E, int L>
+__device__ __forceinline__ void p59_place(uint32_t (&D)[4 * L], int e, uint32_t lo, uint32_t f)
+{
+  const int o = 27 * e, i = E + o / 32, sh = o % 32;
+  D[e] = lo;
+  D[i] |= f << sh;
+  if (sh > 5) D[i + 1] |= f >> (32 - sh);
+}
+
+// MODE = SW_PLAIN: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no column test.
+// Rows in pieces (every other mode): the stride a.ld = G_phi * E may be smaller than G*R; the slots from tb on then
+// also hold columns past the end of the row, whose loads and stores are masked.
+template <int G, int R, int MODE>
 __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 {
-  constexpr bool F48 = WL != WL_PLAIN;           // (historic name) any packed layout
-  const uint32_t LD = F48 ? a.ld : (uint32_t)(G * R);
-  __shared__ uint32_t pkbuf[F48 ? 512 * R : 1];  // 256/G groups x (<= 2*G*R dwords of packed row)
+  constexpr bool PIECES = MODE != SW_PLAIN;
+  constexpr bool LDSPK = MODE == SW_LDS_F48 || MODE == SW_LDS_P59;
+  const uint32_t LD = PIECES ? a.ld : (uint32_t)(G * R);
+  __shared__ uint32_t pkbuf[LDSPK ? 512 * R : 1];  // 256/G groups x (<= 2*G*R dwords of packed row)
   __shared__ double red[4][G * R];       // per-wave column partials
+  if (a.flags[0] & 4u) return;           // a pass has found W unusable (phi_pass_skips): nothing runs until the host has dealt with it
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane % G, q = lane / G;
   const uint32_t K = a.K;
   const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
   const uint32_t ngrp = (gridDim.x * blockDim.x) / G;
+  if (a.colsum_used && blockIdx.x == 0)            // what this rate is built from, kept for the export and for a repeat
+    for (uint32_t c = threadIdx.x; c < LD; c += blockDim.x) a.colsum_used[c] = a.colsum_oth[c];
 
   // Slot t of a lane is column g + G*t.  Slots below tb = K / G hold factor columns in
   // every lane: rate = prior(row) + column sum of the other side, E enters the sums -- no
@@ -792,13 +986,14 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
   const double rate_bias = a.r_prior + a.bias_rate_add;
   const double s_prior = a.s_prior;
   const bool hier = a.hier != 0;
+  bool flushed = false;
 
   // software pipeline: the next row's raw sums and prior are loaded before this row is
   // worked on (the ~90 fp64 instructions per element then cover the load latency)
   double snx[R]; double prn = a.r_prior;
   if (grp < a.rows) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) snx[t] = (!F48 || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)grp * LD + g + G * t] : 0.0;
+    for (int t = 0; t < R; ++t) snx[t] = (!PIECES || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)grp * LD + g + G * t] : 0.0;
     if (hier) prn = a.prior_E[grp];
   }
   for (uint32_t row = grp; row < a.rows; row += ngrp) {
@@ -810,7 +1005,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     const uint32_t nr = row + ngrp;
     if (nr < a.rows) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) snx[t] = (!F48 || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)nr * LD + g + G * t] : 0.0;
+      for (int t = 0; t < R; ++t) snx[t] = (!PIECES || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)nr * LD + g + G * t] : 0.0;
       if (hier) prn = a.prior_E[nr];
     }
     double wmax = 0.0, rsum = 0.0;
@@ -840,18 +1035,77 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     wmax = group_max<G>(wmax);
     rsum = group_sum<G>(rsum);
     const double inv = (wmax > 0.0) ? fast_rcp(wmax) : 0.0;
-    if (F48) {
+    if constexpr (MODE == SW_REG_P59) {
+      // The pass gives a nonzero GP = G/2 lanes; packed lane gp holds the elements e = 0..E-1 of the columns
+      // e*GP + gp.  This sweep's lane g = gp + GP*h owns the slots t, i.e. the columns g + G*t = (h + 2t)*GP + gp:
+      // the elements e = h + 2t of packed lane gp -- the even ones (h = 0) or the odd ones (h = 1).  The two lanes
+      // swap their (low word, 27-bit field) pairs, each then holds all E elements and builds the lane's 4L dwords
+      // with compile-time shifts; h = 0 stores the even 16-byte pieces, h = 1 the odd ones.  No LDS, no atomics.
+      using P = p59_of_slots<R>;
+      if constexpr (P::valid) {
+        constexpr int E = P::E, L = P::L, GP = G / 2;
+        const int gp = g % GP;
+        const bool h = g >= GP;
+        uint32_t D[4 * L];
+#pragma unroll
+        for (int i = 0; i < 4 * L; ++i) D[i] = 0u;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          const bool pair = 2 * t + 1 < E;                // element 2t + 1 exists (E odd: the last slot of h = 1 is past the row)
+          const double v = w[t] * inv;
+          const uint32_t vhi = (uint32_t)__double2hiint(v), vlo = (uint32_t)__double2loint(v);
+          const bool live = pair || !h;
+          // representable: exponent field 897..1023, i.e. 2^-126 <= w < 2 (see p59_put)
+          const bool tiny = vhi < 0x38100000u || vhi >= 0x40000000u;
+          flushed |= live && tiny && !(vhi == 0u && vlo == 0u);
+          const uint32_t of = (tiny || !live) ? 0u : vhi - 0x38000000u, ol = (tiny || !live) ? 0u : vlo;
+          const uint32_t pf = lane_xor<GP>(of), pl = lane_xor<GP>(ol);
+          p59_place<E, L>(D, 2 * t, h ? pl : ol, h ? pf : of);
+          if (pair) p59_place<E, L>(D, 2 * t + 1, h ? ol : pl, h ? of : pf);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>((unsigned char *)a.W + (size_t)row * (size_t)(GP * L * 16)) + gp;
+#pragma unroll
+        for (int j = 0; 2 * j < L; ++j) {
+          const int p0 = 2 * j, p1 = 2 * j + 1;
+          if (p1 < L) {
+            uint4 o;
+            o.x = h ? D[4 * p1] : D[4 * p0]; o.y = h ? D[4 * p1 + 1] : D[4 * p0 + 1];
+            o.z = h ? D[4 * p1 + 2] : D[4 * p0 + 2]; o.w = h ? D[4 * p1 + 3] : D[4 * p0 + 3];
+            dst[(size_t)(h ? p1 : p0) * GP] = o;
+          } else if (!h) {
+            dst[(size_t)p0 * GP] = make_uint4(D[4 * p0], D[4 * p0 + 1], D[4 * p0 + 2], D[4 * p0 + 3]);
+          }
+        }
+        if (a.W_shadow) {          // the same elements as plain doubles: piece t of packed lane gp, half h
+          double *sd = reinterpret_cast<double *>((unsigned char *)a.W_shadow + (size_t)row * (size_t)a.pks.row_bytes) + 2 * gp + (h ? 1 : 0);
+#pragma unroll
+          for (int t = 0; t < R; ++t) sd[(size_t)t * 2 * GP] = (2 * t + 1 < E || !h) ? w[t] * inv : 0.0;
+        }
+      }
+    } else if constexpr (LDSPK) {
       uint32_t *buf = pkbuf + (threadIdx.x / G) * (2 * G * R);
       packed_clear(buf, a.pk, (uint32_t)g, (uint32_t)G);
-      bool flushed = false;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the group's lanes exchange through LDS: clear, put, copy out
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int t = 0; t < R; ++t)
         if ((uint32_t)(g + G * t) < LD) {
-          if (WL == WL_P59) flushed |= p59_put(buf, a.pk, g + G * t, w[t] * inv);
+          if (MODE == SW_LDS_P59) flushed |= p59_put(buf, a.pk, g + G * t, w[t] * inv);
           else f48_put(buf, a.pk, g + G * t, w[t] * inv);
         }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       packed_copy_out(buf, a.W, row, a.pk, (uint32_t)g, (uint32_t)G);
-      if (flushed) atomicOr(a.flags, 2u);
+      __builtin_amdgcn_wave_barrier();                             // the next row's clear stays behind this copy
+      if (a.W_shadow) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+          if ((uint32_t)(g + G * t) < a.pks.G * a.pks.E) f64_put(a.W_shadow, row, a.pks, g + G * t, (uint32_t)(g + G * t) < LD ? w[t] * inv : 0.0);
+      }
+    } else if constexpr (MODE == SW_F64) {
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if ((uint32_t)(g + G * t) < a.pk.G * a.pk.E) f64_put(a.W, row, a.pk, g + G * t, (uint32_t)(g + G * t) < LD ? w[t] * inv : 0.0);
     } else if (a.w32) {
 #pragma unroll
       for (int t = 0; t < R; ++t) ((float *)a.W)[base + g + G * t] = (float)(w[t] * inv);
@@ -864,6 +1118,7 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
     // only one lane in G would work on -- are prior_update_kernel's, over all rows at once
     if (hier && g == 0) a.prior_rate[row] = a.r_prior + rsum;
   }
+  if (flushed) atomicOr(a.flags, 2u);
 
   // block partial column sums, fixed order: groups of a wave, then waves
 #pragma unroll
@@ -886,8 +1141,9 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
 __global__ __launch_bounds__(256) void prior_update_kernel(double *prior_E, double *prior_used,
                                                            const double *prior_rate, double *prior_elog,
                                                            double *prior_elog_used, uint32_t rows,
-                                                           double prior_shape, double psi_prior_shape)
+                                                           double prior_shape, double psi_prior_shape, const uint32_t *flags)
 {
+  if (flags[0] & 4u) return;
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
     const double rt = prior_rate[r];
     prior_used[r] = prior_E[r];
@@ -948,9 +1204,10 @@ __global__ void elog_kernel(const double *S, const double *prior_used, const dou
 // thread sums a fixed strided subset in order, then a fixed-shape LDS tree --
 // the order depends only on nblocks, so the result is bit-reproducible
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double *part, uint32_t nblocks,
-                                                              uint32_t ld, double *out)
+                                                              uint32_t ld, double *out, const uint32_t *flags)
 {
   __shared__ double red[256];
+  if (flags[0] & 4u) return;
   const uint32_t c = blockIdx.x;
   double s = 0.0;
   for (uint32_t b = threadIdx.x; b < nblocks; b += 256) s += part[(size_t)b * ld + c];
@@ -981,10 +1238,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
 }
 
 // W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
-// wmode: 0 double, 1 float, WL_F48 / WL_P59 the packed layouts (built per row in LDS)
+// wmode: 0 double, 1 float, WL_F48 / WL_P59 the packed layouts (built per row in LDS), WL_F64 plain doubles in
+// interleaved pieces; W_shadow (or NULL): the plain-fp64 copy the tiled share of the other side's pass reads
 __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32_t rows,
                                 uint32_t ld, uint32_t K, int32_t bias_col,
-                                int32_t junk_col, PackedRow pk, uint32_t *flags)
+                                int32_t junk_col, PackedRow pk, void *W_shadow, PackedRow pks, uint32_t *flags)
 {
   __shared__ uint32_t pkbuf[4][2304];            // a packed row per wave (<= 64 lanes x 8 pieces x 16 B + slack)
   const int lane = threadIdx.x & 63;
@@ -992,6 +1250,8 @@ __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W,
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   uint32_t *buf = pkbuf[threadIdx.x >> 6];
   const bool packed = wmode == WL_P59 || wmode == WL_F48;
+  const uint32_t cols = (wmode == WL_F64) ? pk.G * pk.E : ld;          // f64 rows: the padding slots past ld hold zeros
+  const uint32_t scols = W_shadow ? pks.G * pks.E : 0u;
   bool flushed = false;
   for (uint32_t row = wave; row < rows; row += nwaves) {
     double m = -1.0e308;
@@ -1000,18 +1260,53 @@ __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W,
       if (live) m = fmax(m, L[(size_t)row * ld + c]);
     }
     m = group_max<64>(m);
-    if (packed) packed_clear(buf, pk, (uint32_t)lane, 64u);
-    for (uint32_t c = lane; c < ld; c += 64) {
-      const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
-      const double wv = live ? exp(L[(size_t)row * ld + c] - m) : 0.0;
-      if (wmode == WL_P59) flushed |= p59_put(buf, pk, c, wv);
-      else if (wmode == WL_F48) f48_put(buf, pk, c, wv);
-      else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
-      else ((double *)W)[(size_t)row * ld + c] = wv;
+    if (packed) {
+      packed_clear(buf, pk, (uint32_t)lane, 64u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    if (packed) packed_copy_out(buf, W, row, pk, (uint32_t)lane, 64u);
+    for (uint32_t c = lane; c < (cols > scols ? cols : scols); c += 64) {
+      const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
+      const double wv = (live && c < ld) ? exp(L[(size_t)row * ld + c] - m) : 0.0;
+      if (c < cols) {
+        if (wmode == WL_P59) flushed |= p59_put(buf, pk, c, wv);
+        else if (wmode == WL_F48) f48_put(buf, pk, c, wv);
+        else if (wmode == WL_F64) f64_put(W, row, pk, c, wv);
+        else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
+        else ((double *)W)[(size_t)row * ld + c] = wv;
+      }
+      if (c < scols) f64_put(W_shadow, row, pks, c, wv);
+    }
+    if (packed) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      packed_copy_out(buf, W, row, pk, (uint32_t)lane, 64u);
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   if (flushed) atomicOr(flags, 2u);
+}
+
+// the fp64 shadow of rows that exist only in the p59 form (a shadow allocated after the rows were written; a snapshot
+// carries W alone): element for element what codec_p59::get reads, an all-zero element as the exact zero a sweep stores
+__global__ __launch_bounds__(256) void shadow_from_p59_kernel(const void *W, PackedRow pk, void *W_shadow, PackedRow pks, uint32_t rows)
+{
+  const uint64_t cols = (uint64_t)pks.G * pks.E, n = (uint64_t)rows * cols;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t row = i / cols; const uint32_t c = (uint32_t)(i % cols);
+    double v = 0.0;
+    const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
+    if (e < pk.E) {
+      const uint32_t *d = reinterpret_cast<const uint32_t *>((const unsigned char *)W + row * (size_t)pk.row_bytes);
+      const uint32_t lo = d[packed_dword_index(pk, g, e)];
+      const uint32_t o = 27u * e, k = pk.E + o / 32u, sh = o % 32u;
+      uint32_t f = d[packed_dword_index(pk, g, k)] >> sh;
+      if (sh > 5u) f |= d[packed_dword_index(pk, g, k + 1)] << (32u - sh);
+      f &= 0x7ffffffu;
+      if (f | lo) v = __hiloint2double((int)(f | 0x38000000u), (int)lo);
+    }
+    f64_put(W_shadow, row, pks, c, v);
+  }
 }
 
 // ---------------------------------------------------------------------

@@ -92,9 +92,13 @@ typedef struct {
                            /*    sign and four exponent bits carry nothing) when   */
                            /*    that saves a 128-byte line per row -- K = 100:    */
                            /*    six lines instead of seven.  A W below 2^-126 of  */
-                           /*    its row maximum (Elog spread > 88 inside a row)   */
-                           /*    cannot be packed: HPF_ERR_STATE, use 3.           */
-                           /* 3: fp64 in plain rows, never packed.                 */
+                           /*    its row maximum (Elog spread > 88 inside a row;   */
+                           /*    HPF states have 10-20) cannot be packed: the      */
+                           /*    library then moves the rows to plain doubles by   */
+                           /*    itself and goes on with the bits a handle made    */
+                           /*    with 3 has (hpf_work_info.w_fallbacks).           */
+                           /* 3: fp64 as plain doubles, never packed (where 0      */
+                           /*    would pack: in the packed shape's pieces).        */
                            /* 1: EXPERIMENTAL fp32 -- drifts out of the 1e-4       */
                            /*    parity contract after ~30 iterations. */
                            /* 2: OPT-IN 48 bits: the top 48 bits of the fp64 value */
@@ -320,12 +324,19 @@ typedef struct {
   uint32_t ld;                       /* row stride of the device matrices, doubles */
   uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
   uint32_t w_layout;                 /* rows of W: 0 plain (phi_V elements per load), 3 packed 59-bit (lossless),  */
-                                     /* 2 packed 48-bit (w_storage = 2); packed: phi_R = 16-byte pieces per lane   */
+                                     /* 2 packed 48-bit (w_storage = 2), 4 plain doubles in the packed shape's     */
+                                     /* 16-byte pieces (w_storage = 3, or after a fallback); 2-4: phi_R = pieces per lane */
   uint32_t tiles_user, tiles_item;   /* tiled phi pass: tiles of the gathered matrix (0: the side is row-major)   */
   /* ABI v5 */
   uint32_t tile_rows_user, tile_rows_item;   /* gathered rows per tile of that side's pass (0: row-major)          */
   uint64_t heavy_min_nnz_user, heavy_min_nnz_item; /* an owner row with at least this many nonzeros is regrouped  */
                                      /* tile by tile ("heavy"); the others stay row-major in the same launch       */
+  uint32_t w_fallbacks;              /* how often the rows of W moved from the packed form to plain doubles because a    */
+                                     /* state turned up that p59 cannot hold (w_layout then reads 4); 0 or 1            */
+  uint32_t w_shadow_user, w_shadow_item; /* 1: that side's rows also exist as plain doubles, read by the TILED share of */
+                                     /* the other side's pass (instructions, not bytes, bound a gather out of L2)       */
+  uint32_t notes;                    /* bit 0 / 1: the user / item side was left row-major because the device is too     */
+                                     /* small for the tiling's temporaries; bit 2 / 3: because their allocation failed   */
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 
