@@ -74,7 +74,7 @@ class HpfWorkInfo(C.Structure):
         ("graph_replay", C.c_uint32), ("w_layout", C.c_uint32), ("tiles_user", C.c_uint32), ("tiles_item", C.c_uint32),
         ("tile_rows_user", C.c_uint32), ("tile_rows_item", C.c_uint32),
         ("heavy_min_nnz_user", C.c_uint64), ("heavy_min_nnz_item", C.c_uint64),
-        ("w_fallbacks", C.c_uint32), ("w_shadow_user", C.c_uint32), ("w_shadow_item", C.c_uint32), ("notes", C.c_uint32),
+        ("w_fallbacks", C.c_uint32), ("notes", C.c_uint32),
     ]
 
 

@@ -154,11 +154,10 @@ struct Driver {
     {
       hpf_work_info wi;
       if (root() && hpf_get_work_info(h, &wi) == HPF_OK)      // infer.log: how the device side laid the work out
-        env.lerr("device: rows of W %s, %u columns; phi passes: user %s (%u tiles%s), item %s (%u tiles%s)",
+        env.lerr("device: rows of W %s, %u columns; phi passes: user %s (%u tiles), item %s (%u tiles)",
                  wi.w_layout == 3 ? "packed 59-bit (lossless)" : wi.w_layout == 2 ? "48-bit (opt-in)" :
                  wi.w_layout == 4 ? "plain fp64 in 16-byte pieces" : "plain fp64", wi.ld,
-                 wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.w_shadow_item ? ", fp64 shadow of the item rows" : "",
-                 wi.tiles_item ? "tiled" : "row-major", wi.tiles_item, wi.w_shadow_user ? ", fp64 shadow of the user rows" : "");
+                 wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.tiles_item ? "tiled" : "row-major", wi.tiles_item);
     }
 
     if (comm.world > 1 && use_rccl) {                      // bootstrap the RCCL communicator

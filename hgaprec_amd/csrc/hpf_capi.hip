@@ -33,8 +33,6 @@ struct Side {
   uint32_t rows = 0;
   double *S = nullptr, *E = nullptr, *L = nullptr;
   void *W = nullptr;                   // [rows x ld] double, or float in the f32-storage mode; rows of pieces: [rows x pk.row_bytes]
-  void *W_shadow = nullptr;            // plain-fp64 copy of the rows (pks) that the TILED share of the other side's pass gathers
-  bool shadow_stale = false;           // W is current, the shadow is not (allocated later, or W came with a snapshot)
   bool w_from_sweep = false;           // W was written by a sweep (a W-only repeat of it restores it), not derived from Elog
   double *prior_E = nullptr, *prior_used = nullptr, *prior_rate = nullptr;
   double *prior_elog = nullptr, *prior_elog_used = nullptr;   // Elog xi/eta now / as used by the last rate
@@ -82,10 +80,9 @@ struct hpf_handle {
   int wl = WL_PLAIN;                    // layout of W rows: plain, WL_P59 (lossless packing, default where it shortens
                                         // the row) or WL_F48 (w_storage = 2); packed: phiR = 16-byte pieces per lane
   PackedRow pk = {0, 0, 0, 0, 0};
-  PackedRow pks = {0, 0, 0, 0, 0};      // plain-fp64 rows in pieces for the same columns (codec_f64): the shadow the tiled share reads
-                                        // beside p59 rows -- and what the rows become when p59 cannot hold a state (recover_flush)
+  PackedRow pks = {0, 0, 0, 0, 0};      // plain-fp64 rows in pieces for the same columns (codec_f64): what the rows become when p59
+                                        // cannot hold a state (recover_flush)
   int sw_mode = SW_PLAIN;               // how the sweep writes W (row_sweep_kernel MODE)
-  bool use_shadow = true;               // HPF_SHADOW=0 (experimental): tiled segments read the packed rows like everything else
   uint32_t fallbacks = 0;               // automatic moves from p59 rows to plain fp64 rows so far
   uint32_t notes = 0;                   // hpf_work_info.notes
   uint64_t iters_counted = 0;           // iterations launched since the device counter flags[1] was last reset
@@ -230,7 +227,7 @@ void dfree(void *p) { if (p) (void)hipFree(p); }
 void free_side(Side &s, bool S_external)
 {
   if (!S_external) dfree(s.S);
-  dfree(s.E); dfree(s.L); dfree(s.W); dfree(s.W_shadow);
+  dfree(s.E); dfree(s.L); dfree(s.W);
   dfree(s.prior_E); dfree(s.prior_used); dfree(s.prior_rate);
   dfree(s.prior_elog); dfree(s.prior_elog_used);
   dfree(s.colsum_used); dfree(s.colsum_part);
@@ -411,59 +408,22 @@ bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_
   return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, blocks, st) : launch_phipk_g<codec_f48>(G, L, side, a, blocks, st);
 }
 
-// p59 rows, tiled chunks from the fp64 shadow (phi_pass_mixed_kernel)
-template <int G, int L>
-void launch_phimx_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
-{
-  if (side & 1) hipLaunchKernelGGL((phi_pass_mixed_kernel<G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
-  else          hipLaunchKernelGGL((phi_pass_mixed_kernel<G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
-}
 template <int G>
-bool launch_phimx_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
 {
-  switch (L) {
-    case 1: launch_phimx_t<G, 1>(side, a, blocks, st); return true;
-    case 2: launch_phimx_t<G, 2>(side, a, blocks, st); return true;
-    case 3: launch_phimx_t<G, 3>(side, a, blocks, st); return true;
-    case 4: launch_phimx_t<G, 4>(side, a, blocks, st); return true;
-    case 5: launch_phimx_t<G, 5>(side, a, blocks, st); return true;
-    case 6: launch_phimx_t<G, 6>(side, a, blocks, st); return true;
-    case 7: launch_phimx_t<G, 7>(side, a, blocks, st); return true;
-    case 8: launch_phimx_t<G, 8>(side, a, blocks, st); return true;
-  }
-  return false;
-}
-bool launch_phi_mixed(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
-{
-  switch (G) {
-    case 4:  return launch_phimx_l<4>(L, side, a, blocks, st);
-    case 8:  return launch_phimx_l<8>(L, side, a, blocks, st);
-    case 16: return launch_phimx_l<16>(L, side, a, blocks, st);
-    case 32: return launch_phimx_l<32>(L, side, a, blocks, st);
-    case 64: return launch_phimx_l<64>(L, side, a, blocks, st);
-  }
-  return false;
-}
-
-// mixed: the tiled chunks gather rows of (E + 1) / 2 pieces from the shadow, like phi_pass_mixed_kernel (p59 rows only)
-template <int G>
-bool launch_gather_only_l(int L, bool mixed, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
-{
-#define GO(LL) case LL: if (mixed) hipLaunchKernelGGL((gather_only_kernel<G, LL, (codec_p59<LL>::E + 1) / 2>), dim3(blocks), dim3(256), 0, st, a, sink); \
-                        else hipLaunchKernelGGL((gather_only_kernel<G, LL, 0>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
-  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) }
+#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
+  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) }
 #undef GO
-  if (L == 9 && !mixed) { hipLaunchKernelGGL((gather_only_kernel<G, 9, 0>), dim3(blocks), dim3(256), 0, st, a, sink); return true; }
   return false;
 }
-bool launch_gather_only(int G, int L, bool mixed, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
 {
   switch (G) {
-    case 4:  return launch_gather_only_l<4>(L, mixed, a, sink, blocks, st);
-    case 8:  return launch_gather_only_l<8>(L, mixed, a, sink, blocks, st);
-    case 16: return launch_gather_only_l<16>(L, mixed, a, sink, blocks, st);
-    case 32: return launch_gather_only_l<32>(L, mixed, a, sink, blocks, st);
-    case 64: return launch_gather_only_l<64>(L, mixed, a, sink, blocks, st);
+    case 4:  return launch_gather_only_l<4>(L, a, sink, blocks, st);
+    case 8:  return launch_gather_only_l<8>(L, a, sink, blocks, st);
+    case 16: return launch_gather_only_l<16>(L, a, sink, blocks, st);
+    case 32: return launch_gather_only_l<32>(L, a, sink, blocks, st);
+    case 64: return launch_gather_only_l<64>(L, a, sink, blocks, st);
   }
   return false;
 }
@@ -1035,8 +995,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     for (int x = 0; x < 8; ++x) {
       for (auto &rg : q[x]) {
         const uint32_t ch = chunk_of(rg, CH, CHc);
-        const uint32_t tiled_bit = (rg.first >= c0 && rg.second <= c1) ? 0u : 0x80000000u;      // a chunk of runs inside tiles (phi_pass_mixed_kernel)
-        for (uint32_t p0 = rg.first; p0 < rg.second; p0 += std::min(ch, rg.second - p0)) qc[x].push_back(make_uint2(p0, (p0 + std::min(ch, rg.second - p0)) | tiled_bit));
+        for (uint32_t p0 = rg.first; p0 < rg.second; p0 += std::min(ch, rg.second - p0)) qc[x].push_back(make_uint2(p0, p0 + std::min(ch, rg.second - p0)));
       }
       longest = std::max(longest, qc[x].size());
     }
@@ -1075,29 +1034,15 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   return rc;
 }
 
-// The tiled lists of both sides (after device_side_work) and the fp64 shadows they read.  With p59 rows the tiled share of
-// a pass gathers plain doubles (the shadow of the OTHER side's rows): a tile is then 4 MiB of those rows.
+// the tiled lists of both sides (after device_side_work); a tile is 4 MiB of the rows the pass gathers
 int build_work_lists_tiled(hpf_handle *h, uint64_t nnz)
 {
   const uint32_t n = h->u.rows, m = h->it.rows;
   int rc;
-  const bool shadow = h->wl == WL_P59 && h->use_shadow;
-  const size_t rowb = shadow ? (size_t)h->pks.row_bytes : h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : (size_t)h->ld * (h->w32 ? 4 : 8);
+  const size_t rowb = h->wl != WL_PLAIN ? (size_t)h->pk.row_bytes : (size_t)h->ld * (h->w32 ? 4 : 8);
   h->notes &= ~15u;
   if ((rc = build_tiled_side(h, h->u, h->rowptr_dev, m, nnz, rowb))) return rc;     // the user pass gathers item rows
-  if ((rc = build_tiled_side(h, h->it, h->colptr_dev, n, nnz, rowb))) return rc;
-  Side *own[2] = {&h->u, &h->it}, *oth[2] = {&h->it, &h->u};
-  for (int k = 0; k < 2; ++k) {
-    const bool want = shadow && own[k]->tiles != 0;
-    if (!want) { dfree(oth[k]->W_shadow); oth[k]->W_shadow = nullptr; oth[k]->shadow_stale = false; continue; }
-    if (oth[k]->W_shadow) continue;
-    unsigned char *w = nullptr;
-    if ((rc = dalloc(h, &w, (size_t)std::max<uint32_t>(oth[k]->rows, 1u) * h->pks.row_bytes))) return rc;
-    oth[k]->W_shadow = w;
-    oth[k]->shadow_stale = !oth[k]->w_dirty;       // rows already written: transcode them (prepare_derived)
-    h->derived_dirty = true;
-  }
-  return HPF_OK;
+  return build_tiled_side(h, h->it, h->colptr_dev, n, nnz, rowb);
 }
 
 // Item-major view of the ratings, built in HBM: h->u.idx / h->u.val (CSR order)
@@ -1230,12 +1175,12 @@ int prepare_derived(hpf_handle *h)
     bool derived = false;
     for (Side *s : sides) {
       if (!s->rows || !s->w_dirty) continue;
-      s->w_dirty = false; s->w_from_sweep = false; s->shadow_stale = false;
+      s->w_dirty = false; s->w_from_sweep = false;
       derived = true;
       const uint32_t blocks = std::min<uint32_t>((s->rows + 3) / 4, 4096);
       hipLaunchKernelGGL(derive_w_kernel, dim3(blocks), dim3(256), 0, h->stream, s->L, s->W,
                          h->wl != WL_PLAIN ? (uint32_t)h->wl : (uint32_t)h->w32,
-                         s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->pk, s->W_shadow, h->pks, h->flags);
+                         s->rows, h->ld, h->K, s->bias_col, s->junk_col, h->pk, h->flags);
     }
     if (!derived || h->wl != WL_P59 || h->capturing) break;
     // an Elog spread above 88 inside a row: p59 cannot hold the state -- plain rows then, derived again (recover_flush)
@@ -1244,12 +1189,6 @@ int prepare_derived(hpf_handle *h)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!(f[0] & 2u)) break;
     { int rc0 = recover_flush(h, f[0], f[1]); if (rc0) return rc0; }
-  }
-  for (Side *s : sides) {            // a shadow allocated after W was written (a later upload, a snapshot): transcode the rows
-    if (!s->rows || !s->W_shadow || !s->shadow_stale) continue;
-    s->shadow_stale = false;
-    const uint64_t ne = (uint64_t)s->rows * h->pks.G * h->pks.E;
-    hipLaunchKernelGGL(shadow_from_p59_kernel, dim3(grid_for(ne)), dim3(256), 0, h->stream, s->W, h->pk, s->W_shadow, h->pks, s->rows);
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
   {
@@ -1279,23 +1218,16 @@ int prepare_derived(hpf_handle *h)
 
 // rows of W in 16-byte pieces?
 bool rows_in_pieces(const hpf_handle *h) { return h->wl != WL_PLAIN; }
-// the tiled chunks of `own`'s pass read the fp64 shadow of the other side
-bool pass_is_mixed(const hpf_handle *h, const Side &own, const Side &oth)
-{
-  return h->wl == WL_P59 && own.chunks && own.tiles && oth.W_shadow;
-}
-
 int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
   const int side = &own == &h->it ? 1 : 0;
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
-  a.chunks = own.chunks; a.W_oth_tiled = oth.W_shadow; a.ld = h->ld;
+  a.chunks = own.chunks; a.ld = h->ld;
   if (a.nseg) {
     const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-    const bool ok = pass_is_mixed(h, own, oth) ? launch_phi_mixed(h->phiG, h->phiR, side, a, blocks, h->stream)
-                  : rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
+    const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
                                       : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream);
     if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
   } else if (side == 1) {
@@ -1305,13 +1237,9 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   }
   // the event separates the phi kernel from the combine that follows it
   if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
-  // a tiled side's rows carry a partial per tile they meet: a workgroup per row; the cut rows of a row-major list a wave
-  const bool wg = own.tiles != 0 && h->ld <= (uint32_t)HPF_COMBINE_MAXCOLS;
   auto combine = [&](const LongRow *rows, uint32_t nrows, const double *src, double *dst) {
-    if (wg) hipLaunchKernelGGL(combine_partials_wg_kernel, dim3(std::min<uint32_t>(nrows, 65536)), dim3(256), 0, h->stream,
-                               rows, nrows, src, dst, h->ld, h->flags);
-    else hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 16384)), dim3(256), 0, h->stream,
-                            rows, nrows, src, dst, h->ld, h->flags);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 65536)), dim3(256), 0, h->stream,
+                       rows, nrows, src, dst, h->ld, h->flags);
   };
   if (own.ngroup) combine(own.grouprows, own.ngroup, own.partial, own.partial2);     // level 1 of the very long rows: partial -> partial2
   if (own.nlong) combine(own.longrows, own.nlong, own.partial, own.S);
@@ -1323,7 +1251,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 void sweep_args(hpf_handle *h, Side &s, SweepArgs &a)
 {
   a.S = s.S; a.W = s.W; a.w32 = h->w32;
-  a.pk = h->pk; a.pks = h->pks; a.W_shadow = s.W_shadow; a.flags = h->flags;
+  a.pk = h->pk; a.flags = h->flags;
   a.prior_E = s.prior_E; a.prior_rate = s.prior_rate;
   a.psi_prior_shape = host_digamma(h->cfg.s_prior + (double)h->K * h->cfg.s_prior);
   a.colsum_part = s.colsum_part; a.colsum_used = s.colsum_used;
@@ -1338,7 +1266,7 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
   SweepArgs a;
   sweep_args(h, s, a);
   a.colsum_oth = colsum_oth;                 // the kernel also copies it to colsum_used: what the rate was built from (export of *_rate.tsv)
-  s.l_stale = true; s.es_stale = true; s.w_from_sweep = true; s.shadow_stale = false;
+  s.l_stale = true; s.es_stale = true; s.w_from_sweep = true;
   if (!launch_sweep(h->sw_mode, h->swG, h->swR, a, s.sweep_blocks, st)) {
     h->err = "no sweep kernel for this configuration"; return HPF_ERR_UNSUPPORTED;
   }
@@ -1450,7 +1378,7 @@ int iterate_global(hpf_handle *h)
 
 void drop_graph(hpf_handle *h);
 
-// p59 rows -> plain doubles in the same shape (codec_f64): W reallocated, the shadows dropped, the work lists cut again
+// p59 rows -> plain doubles in the same shape (codec_f64): W reallocated, the work lists cut again
 // for the new row size -- exactly what a handle created with w_storage = 3 holds
 int set_rows_f64(hpf_handle *h)
 {
@@ -1460,7 +1388,7 @@ int set_rows_f64(hpf_handle *h)
   h->sw_mode = SW_F64;
   Side *sides[2] = {&h->u, &h->it};
   for (Side *s : sides) {
-    dfree(s->W); s->W = nullptr; dfree(s->W_shadow); s->W_shadow = nullptr; s->shadow_stale = false;
+    dfree(s->W); s->W = nullptr;
     unsigned char *w = nullptr;
     if ((rc = dalloc(h, &w, w_bytes(h, s->rows)))) return rc;
     s->W = w;
@@ -1558,7 +1486,7 @@ int iterate_graph(hpf_handle *h, int n_iters)
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
     h->u.l_stale = h->u.es_stale = h->it.l_stale = h->it.es_stale = true;
-    h->u.w_from_sweep = h->it.w_from_sweep = true; h->u.shadow_stale = h->it.shadow_stale = false;
+    h->u.w_from_sweep = h->it.w_from_sweep = true;
     h->ev_count++;
     h->iterations++;
     h->iters_counted++;
@@ -1743,7 +1671,6 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   }
   if (const char *e = knob("HPF_SWEEP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) h->sweep_blocks_max = (uint32_t)v; }
   if (const char *e = knob("HPF_GRAPH")) h->graph_mode = atoi(e) != 0;
-  if (const char *e = knob("HPF_SHADOW")) h->use_shadow = atoi(e) != 0;
   if (const char *e = knob("HPF_SEG_MAX")) { int v = atoi(e); if (v >= 16) h->seg_max = (uint32_t)v; }
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = knob("HPF_TILE")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_mode = v; }
@@ -2371,11 +2298,9 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     Side &s = *sides[k]; const uint32_t f = hd.side_flags[k];
     s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
     s.w_from_sweep = (f & 256u) != 0;
-    s.shadow_stale = s.W_shadow != nullptr && !s.w_dirty;       // the snapshot carries W alone
-    if (s.shadow_stale) h->derived_dirty = true;
   }
-  h->start_sums_done = hd.derived_dirty == 0;  // the tail of the exchange buffer came with the snapshot
-  h->derived_dirty = hd.derived_dirty != 0 || h->derived_dirty;
+  h->derived_dirty = hd.derived_dirty != 0;
+  h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 8, h->stream));
@@ -2685,7 +2610,6 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->tile_rows_user = h->u.tile_rows; out->tile_rows_item = h->it.tile_rows;
   out->heavy_min_nnz_user = h->u.tiles ? h->u.light_below : 0; out->heavy_min_nnz_item = h->it.tiles ? h->it.light_below : 0;
   out->w_fallbacks = h->fallbacks;
-  out->w_shadow_user = h->u.W_shadow ? 1u : 0u; out->w_shadow_item = h->it.W_shadow ? 1u : 0u;
   out->notes = h->notes;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
@@ -2703,8 +2627,7 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = nullptr; a.partial = nullptr; a.flags = h->flags;
-  a.chunks = own.chunks; a.W_oth_tiled = oth.W_shadow; a.ld = h->ld;
-  const bool mixed = pass_is_mixed(h, own, oth);
+  a.chunks = own.chunks; a.ld = h->ld;
   *ms_out = 0.0f;
   if (!a.nseg) return HPF_OK;
   uint32_t *sink = nullptr;
@@ -2713,10 +2636,10 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, mixed, a, sink, blocks, h->stream);      // warm-up
+  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);      // warm-up
   if (ok) {
     e = hipEventRecord(e0, h->stream);
-    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, mixed, a, sink, blocks, h->stream);
+    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);
     if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -2824,7 +2747,7 @@ int hpf_algorithmic_bytes(hpf_handle *h, uint64_t *phi_user, uint64_t *phi_item,
   // counted), so phi_user + phi_item == B_phi of SURVEY.md exactly.
   const uint64_t Kp = h->K + (h->cfg.bias ? 1u : 0u), nnz = h->nnz;
   const uint64_t by = h->u.val ? 1u : 0u, n = h->u.rows, m = h->it.rows;
-  const uint64_t seb = h->w32 ? 32 : h->wl == WL_F48 ? 48 : h->wl == WL_P59 ? 59 : 64, sa = 8;   // (the fp64 shadow of the tiled share: still 59 -- what HAS to move)   // BITS per stored W element; bytes per accumulator
+  const uint64_t seb = h->w32 ? 32 : h->wl == WL_F48 ? 48 : h->wl == WL_P59 ? 59 : 64, sa = 8;   // BITS per stored W element; bytes per accumulator
   if (phi_user) *phi_user = nnz * (4 + by) + 8 * (n + 1) + nnz * Kp * seb / 8 + n * Kp * seb / 8 + n * Kp * sa;
   if (phi_item) *phi_item = nnz * Kp * seb / 8;
   if (rows) *rows = (n + m) * Kp * 2 * sa + (n + m) * Kp * 2 * seb / 8 + 64 * (n + m);

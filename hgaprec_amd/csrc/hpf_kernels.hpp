@@ -125,14 +125,10 @@ struct PhiArgs {
                             // entry the p59 rows cannot hold; bit 2: a pass has seen bit 1 -- everything launched since is a
                             // no-op until the host has switched the row layout (hpf_capi.hip, recover_flush)
                             // [1] iterations begun with bits 1 and 2 clear (counted by the item-major pass, which opens an iteration)
-  // tiled pass (hpf_build.hpp): workgroup b works on the segments [chunks[b].x, chunks[b].y & 0x7fffffff), one wave
+  // tiled pass (hpf_build.hpp): workgroup b works on the segments [chunks[b].x, chunks[b].y), one wave
   // per segment in turn; the host lays the chunks out so that b % 8 -- the XCD a workgroup lands on --
-  // walks one tile after another.  NULL: the waves stride over the whole list.  Bit 31 of chunks[b].y marks a chunk
-  // of TILED segments (runs inside one tile of the gathered matrix): phi_pass_mixed_kernel gathers those from
-  // W_oth_tiled, the plain-fp64 copy of the gathered rows -- they come out of the XCD's L2, where instructions,
-  // not bytes, are what a gather costs -- and everything else from the packed rows W_oth.
+  // walks one tile after another.  NULL: the waves stride over the whole list.
   const uint2    *chunks;
-  const void     *W_oth_tiled;
   uint32_t        ld;       // row stride of S_own / partial, columns (layouts whose rows do not fix it: codec_f64)
 };
 
@@ -158,7 +154,7 @@ __device__ __forceinline__ SegRange seg_range(const PhiArgs &a)
   if (a.chunks) {
     const uint2 c = a.chunks[blockIdx.x];
     r.s = __builtin_amdgcn_readfirstlane(c.x + (threadIdx.x >> 6));
-    r.end = __builtin_amdgcn_readfirstlane(c.y & 0x7fffffffu);
+    r.end = __builtin_amdgcn_readfirstlane(c.y);
     r.step = blockDim.x >> 6;
   } else {
     r.s = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -331,8 +327,8 @@ __global__ __launch_bounds__(256) void phi_pass_kernel(PhiArgs a)
 // Arithmetic and accumulators are fp64 in every mode.
 // ---------------------------------------------------------------------
 //   f64  plain fp64 elements in the same interleaved pieces, two per piece (E = 2L).  What a handle falls back to
-//        when a state turns up that p59 cannot hold (hpf_capi.hip, recover_flush), what hpf_config.w_storage = 3
-//        asks for from the start, and the layout of the SHADOW copy the tiled share of a pass gathers from.
+//        when a state turns up that p59 cannot hold (hpf_capi.hip, recover_flush) and what hpf_config.w_storage = 3
+//        asks for from the start.
 //        The row stride of S / partial stays that of the packed shape it stands in for (PhiArgs::ld <= G * E).
 enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3, WL_F64 = 4 };      // layout codes (hpf_work_info.w_layout)
 
@@ -592,30 +588,6 @@ __global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
-// p59 rows; the chunks of TILED segments gather from the plain-fp64 shadow of the other side's rows (round 4).
-// A gather that hits the XCD's own L2 costs instructions, not bytes, and the 59-bit decode was 39 % of the
-// tiled share's VALU work: there the rows are read as plain doubles (7 lines instead of 6 at K = 100 -- out of
-// L2), everywhere else -- every gather that crosses the fabric -- in the packed form.  The branch is per
-// workgroup (a chunk holds one kind of segment); a tile is sized in bytes of the rows it is read from.
-template <int G, int L, int SIDE>
-__global__ __launch_bounds__(256, 3) void phi_pass_mixed_kernel(PhiArgs a)
-{
-  constexpr int LS = (codec_p59<L>::E + 1) / 2;
-  if (phi_pass_skips(a, SIDE)) return;
-  const int lane = threadIdx.x & 63;
-  const SegRange sr = seg_range(a);
-  const bool tiled = (a.chunks[blockIdx.x].y >> 31) != 0u;             // wave-uniform
-  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)(lane % G) * 16;
-  bool underflow = false;
-  if (tiled)
-    phi_segments<codec_p59<L>, codec_f64<LS>, G, L, LS>(a, sr, W_own, (const unsigned char *)a.W_oth_tiled + (size_t)(lane % G) * 16,
-                                                        lane, underflow);
-  else
-    phi_segments<codec_p59<L>, codec_p59<L>, G, L, L>(a, sr, W_own, (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16,
-                                                      lane, underflow);
-  if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
-}
-
 // ---------------------------------------------------------------------
 // Measurement only (hpf_gather_only): a phi pass with the arithmetic taken out.  Same work
 // list, same index stream, same rows, same two register sets -- the gathered pieces are folded
@@ -700,20 +672,14 @@ __device__ __forceinline__ void gather_only_segments(const PhiArgs &a, const Seg
   }
 }
 
-// LS > 0: the chunks of tiled segments gather rows of LS pieces from a.W_oth_tiled, like phi_pass_mixed_kernel
-template <int G, int L, int LS>
+template <int G, int L>
 __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *sink)
 {
   const int lane = threadIdx.x & 63;
   const SegRange sr = seg_range(a);
-  const unsigned char *W_own = (const unsigned char *)a.W_own + (size_t)(lane % G) * 16;
   uint4 acc = {0u, 0u, 0u, 0u};
-  bool tiled = false;
-  if constexpr (LS > 0) tiled = a.chunks && (a.chunks[blockIdx.x].y >> 31) != 0u;
-  if constexpr (LS > 0) {
-    if (tiled) gather_only_segments<G, L, LS>(a, sr, W_own, (const unsigned char *)a.W_oth_tiled + (size_t)(lane % G) * 16, lane, acc);
-  }
-  if (!tiled) gather_only_segments<G, L, L>(a, sr, W_own, (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, acc);
+  gather_only_segments<G, L, L>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
+                                (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, acc);
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;      // keeps the loads alive
 }
 
@@ -741,52 +707,48 @@ __device__ __forceinline__ void combine_columns(const double *partial, uint32_t 
   s0[0] = a0; s1[0] = a1;
 }
 
+// A block takes four rows.  Rows of up to COMBINE_SPLIT partials: a wave each, as before.  Rows with more (round 4) --
+// a tiled side's heavy rows carry one partial per tile they meet, C2's items 184, C4's 176 -- are then worked on by
+// the whole workgroup, one after the other: the four waves take a quarter of the slots each (contiguous quarters, cut
+// by the slot count alone) and the four sums are added in wave order.  Which of the two a row gets, and hence the
+// order of its sum, is a function of its slot count: the same bits on every run.
+constexpr uint32_t COMBINE_SPLIT = 64;
 __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
                                                                const double *partial, double *S, uint32_t ld,
                                                                const uint32_t *flags)
 {
-  if (flags[0] & 6u) return;                       // the pass before it did not run (phi_pass_skips)
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t r = wave; r < nrows; r += nwaves) {
-    const LongRow lr = rows[r];
-    for (uint32_t c = lane; c < ld; c += 128) {
-      double s0[1], s1[1];
-      combine_columns(partial, lr.first_slot, lr.nslots, ld, lane, s0, s1, c);
-      double *d = S + (size_t)lr.row * ld + c;
-      d[0] = s0[0];
-      if (c + 64 < ld) d[64] = s1[0];
-    }
-  }
-}
-
-// The same sum with a WORKGROUP per row (round 4): rows of a tiled side carry one partial per tile they meet
-// (C2's heavy items: 184, C4's: 176) and a single wave walking that chain is a latency chain of a dozen round
-// trips while most of the chip idles.  The four waves take a quarter of the slots each -- contiguous quarters,
-// cut by the slot count alone -- and the four sums are added in wave order: a fixed tree, the same bits on
-// every run (the order differs from the one-wave kernel's, which is why a side uses one of the two throughout).
-__global__ __launch_bounds__(256) void combine_partials_wg_kernel(const LongRow *rows, uint32_t nrows,
-                                                                  const double *partial, double *S, uint32_t ld,
-                                                                  const uint32_t *flags)
-{
-  if (flags[0] & 6u) return;
   __shared__ double part[4][HPF_COMBINE_MAXCOLS];
+  if (flags[0] & 6u) return;                       // the pass before it did not run (phi_pass_skips)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
-    const LongRow lr = rows[r];
-    const uint32_t per = (lr.nslots + 3) / 4;
-    const uint32_t q0 = min(per * wv, lr.nslots), q1 = min(q0 + per, lr.nslots);
-    for (uint32_t c = lane; c < ld; c += 128) {
-      double s0[1], s1[1];
-      combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, lane, s0, s1, c);
-      part[wv][c] = s0[0];
-      if (c + 64 < ld) part[wv][c + 64] = s1[0];
+  for (uint32_t r0 = blockIdx.x * 4; r0 < nrows; r0 += gridDim.x * 4) {
+    const uint32_t r = r0 + wv;
+    if (r < nrows) {
+      const LongRow lr = rows[r];
+      if (lr.nslots <= COMBINE_SPLIT)
+        for (uint32_t c = lane; c < ld; c += 128) {
+          double s0[1], s1[1];
+          combine_columns(partial, lr.first_slot, lr.nslots, ld, lane, s0, s1, c);
+          double *d = S + (size_t)lr.row * ld + c;
+          d[0] = s0[0];
+          if (c + 64 < ld) d[64] = s1[0];
+        }
     }
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < ld; c += 256)
-      S[(size_t)lr.row * ld + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
-    __syncthreads();
+    for (uint32_t k = 0; k < 4 && r0 + k < nrows; ++k) {           // block-uniform: every thread reads the same record
+      const LongRow lr = rows[r0 + k];
+      if (lr.nslots <= COMBINE_SPLIT) continue;
+      const uint32_t per = (lr.nslots + 3) / 4;
+      const uint32_t q0 = min(per * wv, lr.nslots), q1 = min(q0 + per, lr.nslots);
+      for (uint32_t c = lane; c < ld; c += 128) {
+        double s0[1], s1[1];
+        combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, lane, s0, s1, c);
+        part[wv][c] = s0[0];
+        if (c + 64 < ld) part[wv][c + 64] = s1[0];
+      }
+      __syncthreads();
+      for (uint32_t c = threadIdx.x; c < ld; c += 256)
+        S[(size_t)lr.row * ld + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      __syncthreads();
+    }
   }
 }
 
@@ -904,8 +866,6 @@ struct SweepArgs {
   double       *colsum_part;// [nblocks x ld]
   uint32_t      rows, ld, K;
   PackedRow     pk;         // rows of W in 16-byte pieces (every mode but SW_PLAIN): the phi kernel's G, E, L and the row bytes
-  void         *W_shadow;   // plain-fp64 copy of the rows for the tiled share of the other side's pass, or NULL
-  PackedRow     pks;        // its shape
   uint32_t     *flags;      // bit 1: a nonzero W below 2^-126 was flushed by the p59 layout; bit 2: do not run
   int32_t       bias_col;   // column holding this side's bias (-1: none)
   int32_t       junk_col;   // column holding the other side's bias (-1: none)
@@ -1063,23 +1023,21 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
           p59_place<E, L>(D, 2 * t, h ? pl : ol, h ? pf : of);
           if (pair) p59_place<E, L>(D, 2 * t + 1, h ? ol : pl, h ? of : pf);
         }
-        uint4 *dst = reinterpret_cast<uint4 *>((unsigned char *)a.W + (size_t)row * (size_t)(GP * L * 16)) + gp;
+        // h = 0 stores the even pieces, h = 1 the odd ones.  The choice is ARITHMETIC (v_bfi_b32 under a lane mask): written
+        // as a select between two elements of D the compiler turns it into a run-time index into the register array --
+        // a chain of 24 compares per word
+        const uint32_t hm = h ? 0xffffffffu : 0u;
+        auto pick = [&](uint32_t odd, uint32_t even) -> uint32_t { return (odd & hm) | (even & ~hm); };
+        uint4 *dst = reinterpret_cast<uint4 *>((unsigned char *)a.W + (size_t)row * (size_t)(GP * L * 16)) + gp + (h ? GP : 0);
 #pragma unroll
         for (int j = 0; 2 * j < L; ++j) {
           const int p0 = 2 * j, p1 = 2 * j + 1;
           if (p1 < L) {
-            uint4 o;
-            o.x = h ? D[4 * p1] : D[4 * p0]; o.y = h ? D[4 * p1 + 1] : D[4 * p0 + 1];
-            o.z = h ? D[4 * p1 + 2] : D[4 * p0 + 2]; o.w = h ? D[4 * p1 + 3] : D[4 * p0 + 3];
-            dst[(size_t)(h ? p1 : p0) * GP] = o;
+            dst[(size_t)p0 * GP] = make_uint4(pick(D[4 * p1], D[4 * p0]), pick(D[4 * p1 + 1], D[4 * p0 + 1]),
+                                              pick(D[4 * p1 + 2], D[4 * p0 + 2]), pick(D[4 * p1 + 3], D[4 * p0 + 3]));
           } else if (!h) {
             dst[(size_t)p0 * GP] = make_uint4(D[4 * p0], D[4 * p0 + 1], D[4 * p0 + 2], D[4 * p0 + 3]);
           }
-        }
-        if (a.W_shadow) {          // the same elements as plain doubles: piece t of packed lane gp, half h
-          double *sd = reinterpret_cast<double *>((unsigned char *)a.W_shadow + (size_t)row * (size_t)a.pks.row_bytes) + 2 * gp + (h ? 1 : 0);
-#pragma unroll
-          for (int t = 0; t < R; ++t) sd[(size_t)t * 2 * GP] = (2 * t + 1 < E || !h) ? w[t] * inv : 0.0;
         }
       }
     } else if constexpr (LDSPK) {
@@ -1097,11 +1055,6 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
       __builtin_amdgcn_wave_barrier();
       packed_copy_out(buf, a.W, row, a.pk, (uint32_t)g, (uint32_t)G);
       __builtin_amdgcn_wave_barrier();                             // the next row's clear stays behind this copy
-      if (a.W_shadow) {
-#pragma unroll
-        for (int t = 0; t < R; ++t)
-          if ((uint32_t)(g + G * t) < a.pks.G * a.pks.E) f64_put(a.W_shadow, row, a.pks, g + G * t, (uint32_t)(g + G * t) < LD ? w[t] * inv : 0.0);
-      }
     } else if constexpr (MODE == SW_F64) {
 #pragma unroll
       for (int t = 0; t < R; ++t)
@@ -1239,10 +1192,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *E,
 
 // W = exp(L - rowmax(L)) over the live columns (after hpf_set_state(ELOG))
 // wmode: 0 double, 1 float, WL_F48 / WL_P59 the packed layouts (built per row in LDS), WL_F64 plain doubles in
-// interleaved pieces; W_shadow (or NULL): the plain-fp64 copy the tiled share of the other side's pass reads
+// interleaved pieces
 __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W, uint32_t wmode, uint32_t rows,
                                 uint32_t ld, uint32_t K, int32_t bias_col,
-                                int32_t junk_col, PackedRow pk, void *W_shadow, PackedRow pks, uint32_t *flags)
+                                int32_t junk_col, PackedRow pk, uint32_t *flags)
 {
   __shared__ uint32_t pkbuf[4][2304];            // a packed row per wave (<= 64 lanes x 8 pieces x 16 B + slack)
   const int lane = threadIdx.x & 63;
@@ -1251,7 +1204,6 @@ __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W,
   uint32_t *buf = pkbuf[threadIdx.x >> 6];
   const bool packed = wmode == WL_P59 || wmode == WL_F48;
   const uint32_t cols = (wmode == WL_F64) ? pk.G * pk.E : ld;          // f64 rows: the padding slots past ld hold zeros
-  const uint32_t scols = W_shadow ? pks.G * pks.E : 0u;
   bool flushed = false;
   for (uint32_t row = wave; row < rows; row += nwaves) {
     double m = -1.0e308;
@@ -1265,17 +1217,14 @@ __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    for (uint32_t c = lane; c < (cols > scols ? cols : scols); c += 64) {
+    for (uint32_t c = lane; c < cols; c += 64) {
       const bool live = c < K || (int32_t)c == bias_col || (int32_t)c == junk_col;
       const double wv = (live && c < ld) ? exp(L[(size_t)row * ld + c] - m) : 0.0;
-      if (c < cols) {
-        if (wmode == WL_P59) flushed |= p59_put(buf, pk, c, wv);
-        else if (wmode == WL_F48) f48_put(buf, pk, c, wv);
-        else if (wmode == WL_F64) f64_put(W, row, pk, c, wv);
-        else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
-        else ((double *)W)[(size_t)row * ld + c] = wv;
-      }
-      if (c < scols) f64_put(W_shadow, row, pks, c, wv);
+      if (wmode == WL_P59) flushed |= p59_put(buf, pk, c, wv);
+      else if (wmode == WL_F48) f48_put(buf, pk, c, wv);
+      else if (wmode == WL_F64) f64_put(W, row, pk, c, wv);
+      else if (wmode == 1) ((float *)W)[(size_t)row * ld + c] = (float)wv;
+      else ((double *)W)[(size_t)row * ld + c] = wv;
     }
     if (packed) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1285,28 +1234,6 @@ __global__ __launch_bounds__(256) void derive_w_kernel(const double *L, void *W,
     }
   }
   if (flushed) atomicOr(flags, 2u);
-}
-
-// the fp64 shadow of rows that exist only in the p59 form (a shadow allocated after the rows were written; a snapshot
-// carries W alone): element for element what codec_p59::get reads, an all-zero element as the exact zero a sweep stores
-__global__ __launch_bounds__(256) void shadow_from_p59_kernel(const void *W, PackedRow pk, void *W_shadow, PackedRow pks, uint32_t rows)
-{
-  const uint64_t cols = (uint64_t)pks.G * pks.E, n = (uint64_t)rows * cols;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t row = i / cols; const uint32_t c = (uint32_t)(i % cols);
-    double v = 0.0;
-    const uint32_t g = c & (pk.G - 1u), e = c >> pk.lgG;
-    if (e < pk.E) {
-      const uint32_t *d = reinterpret_cast<const uint32_t *>((const unsigned char *)W + row * (size_t)pk.row_bytes);
-      const uint32_t lo = d[packed_dword_index(pk, g, e)];
-      const uint32_t o = 27u * e, k = pk.E + o / 32u, sh = o % 32u;
-      uint32_t f = d[packed_dword_index(pk, g, k)] >> sh;
-      if (sh > 5u) f |= d[packed_dword_index(pk, g, k + 1)] << (32u - sh);
-      f &= 0x7ffffffu;
-      if (f | lo) v = __hiloint2double((int)(f | 0x38000000u), (int)lo);
-    }
-    f64_put(W_shadow, row, pks, c, v);
-  }
 }
 
 // ---------------------------------------------------------------------

@@ -333,8 +333,6 @@ typedef struct {
                                      /* tile by tile ("heavy"); the others stay row-major in the same launch       */
   uint32_t w_fallbacks;              /* how often the rows of W moved from the packed form to plain doubles because a    */
                                      /* state turned up that p59 cannot hold (w_layout then reads 4); 0 or 1            */
-  uint32_t w_shadow_user, w_shadow_item; /* 1: that side's rows also exist as plain doubles, read by the TILED share of */
-                                     /* the other side's pass (instructions, not bytes, bound a gather out of L2)       */
   uint32_t notes;                    /* bit 0 / 1: the user / item side was left row-major because the device is too     */
                                      /* small for the tiling's temporaries; bit 2 / 3: because their allocation failed   */
 } hpf_work_info;

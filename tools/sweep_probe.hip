@@ -1,7 +1,6 @@
 // tools/sweep_probe.hip -- the row sweep on its own (measurement tool, not part of the library): the kernel of
 // hpf_kernels.hpp at C2's user-side shape (1M rows, K = 100, ld = 104; G = 16, R = 7) in each way of writing W --
-// plain rows, p59 built in LDS (round 3), p59 built in registers (round 4), plain doubles in pieces, and the
-// register form with the fp64 shadow beside it.  Prints ms per launch and the bytes moved.
+// plain rows, p59 built in LDS (round 3), p59 built in registers (round 4), plain doubles in pieces.  Prints ms per launch and the bytes moved.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/sweep_probe tools/sweep_probe.hip && tools/sweep_probe [rows]
 #include "../hgaprec_amd/csrc/hpf_kernels.hpp"
 #include <cstdio>
@@ -31,18 +30,19 @@ int main(int argc, char **argv)
   std::vector<double> S((size_t)rows * ld), cs(ld, 3.0e4);
   unsigned long long x = 88172645463325252ull;
   for (auto &v : S) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 40.0; }
-  double *dS, *dcs, *dpart, *dprior, *drate, *dused; void *dW, *dWs; uint32_t *dflags;
+  double *dS, *dcs, *dpart, *dprior, *drate, *dused; void *dW; uint32_t *dflags;
   const uint32_t blocks = 2048;
   CK(hipMalloc(&dS, S.size() * 8)); CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dcs, ld * 8)); CK(hipMemcpy(dcs, cs.data(), ld * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dpart, (size_t)blocks * 112 * 8)); CK(hipMalloc(&dprior, (size_t)rows * 8)); CK(hipMalloc(&drate, (size_t)rows * 8));
-  CK(hipMalloc(&dused, ld * 8)); CK(hipMalloc(&dW, (size_t)rows * 896)); CK(hipMalloc(&dWs, (size_t)rows * 896));
+  CK(hipMalloc(&dused, ld * 8)); CK(hipMalloc(&dW, (size_t)rows * 896));
   CK(hipMalloc(&dflags, 16)); CK(hipMemset(dflags, 0, 16));
   CK(hipMemset(dprior, 0, (size_t)rows * 8));
   SweepArgs a;
   a.S = dS; a.W = dW; a.w32 = 0; a.prior_E = dprior; a.prior_rate = drate; a.psi_prior_shape = 0.0;
   a.colsum_oth = dcs; a.colsum_used = dused; a.colsum_part = dpart; a.rows = rows; a.ld = ld; a.K = K;
-  a.pk = {8, 13, 6, 768, 3}; a.pks = {8, 14, 7, 896, 3}; a.W_shadow = nullptr; a.flags = dflags;
+  a.pk = {8, 13, 6, 768, 3}; a.flags = dflags;
+  const PackedRow pkf = {8, 14, 7, 896, 3};
   a.bias_col = -1; a.junk_col = -1; a.bias_rate_add = 0.0; a.s_prior = 0.3; a.r_prior = 0.3; a.hier = 1;
   const int reps = 20;
   printf("{\"rows\": %u, \"ld\": %u", rows, ld);
@@ -52,8 +52,7 @@ int main(int argc, char **argv)
   }
   printf(", \"p59_lds_ms\": %.4f", run<G, R, SW_LDS_P59>(a, blocks, reps));
   printf(", \"p59_reg_ms\": %.4f", run<G, R, SW_REG_P59>(a, blocks, reps));
-  { SweepArgs f = a; f.pk = a.pks; printf(", \"f64_pieces_ms\": %.4f", run<G, R, SW_F64>(f, blocks, reps)); }
-  { SweepArgs f = a; f.W_shadow = dWs; printf(", \"p59_reg_shadow_ms\": %.4f", run<G, R, SW_REG_P59>(f, blocks, reps)); }
+  { SweepArgs f = a; f.pk = pkf; printf(", \"f64_pieces_ms\": %.4f", run<G, R, SW_F64>(f, blocks, reps)); }
   uint32_t fl[4]; CK(hipMemcpy(fl, dflags, 16, hipMemcpyDeviceToHost));
   printf(", \"flags\": %u, \"bytes_read\": %zu, \"bytes_written_p59\": %zu}\n", fl[0], S.size() * 8, (size_t)rows * 768);
   // the two ways of building a p59 row must give the same bytes
