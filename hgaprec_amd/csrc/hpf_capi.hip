@@ -1238,7 +1238,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   // the event separates the phi kernel from the combine that follows it
   if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
   auto combine = [&](const LongRow *rows, uint32_t nrows, const double *src, double *dst) {
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 65536)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 65536)), dim3(256), (size_t)4 * h->ld * 8, h->stream,
                        rows, nrows, src, dst, h->ld, h->flags);
   };
   if (own.ngroup) combine(own.grouprows, own.ngroup, own.partial, own.partial2);     // level 1 of the very long rows: partial -> partial2
@@ -1426,6 +1426,7 @@ int recover_flush(hpf_handle *h, uint32_t fl0, uint32_t begun)
       SweepArgs a;
       sweep_args(h, *s, a);
       a.prior_E = s->prior_used; a.colsum_oth = s->colsum_used; a.colsum_used = nullptr;             // what that sweep read
+      if (!s->es_stale) a.s_prior = 0.0;      // an export has turned S into the shape (prior added, in place) since: the same sum, not taken twice
       if (!launch_sweep(h->sw_mode, h->swG, h->swR, a, s->sweep_blocks, h->stream)) { h->err = "no sweep kernel for this configuration"; rc = HPF_ERR_UNSUPPORTED; break; }
     }
     if (rc || (rc = check_launch(h, "repeat of the sweeps in plain rows"))) break;

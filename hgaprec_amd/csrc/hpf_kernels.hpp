@@ -20,8 +20,6 @@
 
 namespace hpf {
 
-constexpr int HPF_COMBINE_MAXCOLS = 1152;     // widest row stride: 64 lanes x 17 (or 18) elements
-
 // ---------------------------------------------------------------------
 // work item of a phi pass: up to seg_max consecutive nonzeros of ONE owner row
 // ---------------------------------------------------------------------
@@ -717,9 +715,10 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
                                                                const double *partial, double *S, uint32_t ld,
                                                                const uint32_t *flags)
 {
-  __shared__ double part[4][HPF_COMBINE_MAXCOLS];
+  extern __shared__ double combine_part[];         // [4][ld]: the launch sizes it
   if (flags[0] & 6u) return;                       // the pass before it did not run (phi_pass_skips)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double *part0 = combine_part, *mine = combine_part + (size_t)wv * ld;
   for (uint32_t r0 = blockIdx.x * 4; r0 < nrows; r0 += gridDim.x * 4) {
     const uint32_t r = r0 + wv;
     if (r < nrows) {
@@ -741,12 +740,12 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *ro
       for (uint32_t c = lane; c < ld; c += 128) {
         double s0[1], s1[1];
         combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, lane, s0, s1, c);
-        part[wv][c] = s0[0];
-        if (c + 64 < ld) part[wv][c + 64] = s1[0];
+        mine[c] = s0[0];
+        if (c + 64 < ld) mine[c + 64] = s1[0];
       }
       __syncthreads();
       for (uint32_t c = threadIdx.x; c < ld; c += 256)
-        S[(size_t)lr.row * ld + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        S[(size_t)lr.row * ld + c] = ((part0[c] + part0[ld + c]) + part0[2 * ld + c]) + part0[3 * ld + c];
       __syncthreads();
     }
   }

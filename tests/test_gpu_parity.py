@@ -697,11 +697,6 @@ def test_widest_rows_pack_when_the_sweep_has_a_shape_for_them(orc, K, layout):
         assert rel_err(D.get_state(w), M.state(w)) < RTOL, w
 
 
-def _same_state(src, dst, hier, bias):
-    for w in init_states(hier, bias):
-        dst.set_state(w, src.get_state(w) if hasattr(src, "get_state") else src.state(w))
-
-
 def test_default_packs_k100_rows_and_falls_back_when_a_state_does_not_fit(orc):
     """K = 100: 104 columns x 59 bits = 768 bytes, six lines instead of seven, chosen by default.
     A W entry below 2^-126 of its row maximum (an Elog spread above 88 inside a row -- no HPF state
@@ -718,13 +713,13 @@ def test_default_packs_k100_rows_and_falls_back_when_a_state_does_not_fit(orc):
     P = Hpf(n, m, K, hier=True, w_storage=3)
     P.upload_csr(*make_problem(n, m, 4000, 3))
     assert P.work_info()["w_layout"] == 4 and P.work_info()["ld"] == 104
-    el = D.get_state("THETA_ELOG")
-    el[:, 0] -= 120.0                                   # exp(-120) = 7.7e-53 < 2^-126
-    _same_state(D, P, True, False)
-    for w in init_states(True, False):
-        M.set_state(w, D.get_state(w))
+    # the state of the run so far, exported once and handed to all three (D itself included: what it keeps inside --
+    # W from its sweep, column sums from the sweep's own E -- is a rounding away from what the exported arrays give)
+    st = {w: D.get_state(w) for w in init_states(True, False)}
+    st["THETA_ELOG"][:, 0] -= 120.0                     # exp(-120) = 7.7e-53 < 2^-126
     for X in (D, P, M):
-        X.set_state("THETA_ELOG", el)
+        for w, v in st.items():
+            X.set_state(w, v)
     D.iterate(3); P.iterate(3); M.iterate(3)
     wd, wp = D.work_info(), P.work_info()
     assert wd["w_layout"] == 4 and wd["w_fallbacks"] == 1 and wp["w_layout"] == 4 and wp["w_fallbacks"] == 0, (wd, wp)
