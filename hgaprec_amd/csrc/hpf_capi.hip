@@ -46,6 +46,7 @@ struct Side {
   // segments ("long") have their segment sums combined by a second kernel
   Seg *segs = nullptr; uint32_t nseg = 0;
   LongRow *longrows = nullptr; uint32_t nlong = 0;
+  uint32_t nlong_wave = 0;             // the first nlong_wave of them: a wave each; the rest (a tiled side's rows with more than 64 partials) a workgroup each
   double *partial = nullptr; uint32_t npartial = 0;
   // rows with more than HUGE_SLOTS segments are combined in two levels so that
   // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
@@ -691,7 +692,7 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
 {
   dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
   s.segs = nullptr; s.longrows = s.grouprows = s.hugerows = nullptr;
-  s.nseg = s.nlong = s.ngroup = s.nhuge = 0;
+  s.nseg = s.nlong = s.nlong_wave = s.ngroup = s.nhuge = 0;
   dfree(s.partial); dfree(s.partial2);
   s.partial = nullptr; s.partial2 = nullptr;
   s.npartial = 0; s.npartial2 = 0;
@@ -720,7 +721,7 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
     if (e != hipSuccess) { h->err = std::string("seg_plan_kernel: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
     if (hb) { h->err = "row pointers must start at 0 and be monotone"; rc = HPF_ERR_INVALID; break; }
     if (tot[0] > 0xffffffffull || tot[1] > 0x7fffffffull) { h->err = "too many segments for 32-bit work lists"; rc = HPF_ERR_UNSUPPORTED; break; }
-    s.nseg = (uint32_t)tot[0]; s.npartial = (uint32_t)tot[1]; s.nlong = (uint32_t)tot[2];
+    s.nseg = (uint32_t)tot[0]; s.npartial = (uint32_t)tot[1]; s.nlong = s.nlong_wave = (uint32_t)tot[2];
     s.nhuge = (uint32_t)tot[3]; s.ngroup = s.npartial2 = (uint32_t)tot[4];
     if ((rc = dalloc(h, &s.segs, s.nseg)) || (rc = dalloc(h, &s.longrows, s.nlong))) break;
     if (s.ngroup && ((rc = dalloc(h, &s.grouprows, s.ngroup)) || (rc = dalloc(h, &s.hugerows, s.nhuge)))) break;
@@ -788,7 +789,8 @@ uint32_t bits_for(uint64_t count) { uint32_t b = 0; while (b < 32 && ((uint64_t)
 int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_oth, uint64_t nnz, size_t row_bytes)
 {
   if (!((h->tile_sides >> (&s == &h->it ? 1 : 0)) & 1)) return HPF_OK;
-  if (h->tile_mode == 0 || h->cfg.tiling == 1 || nnz == 0 || s.rows == 0 || nnz >= (1ull << 32)) return HPF_OK;
+  if (h->tile_mode == 0 || h->cfg.tiling == 1 || nnz == 0 || s.rows == 0) return HPF_OK;      // (>= 2^32 nonzeros: positions are 64-bit throughout;
+                                                                                              //  segments and partial slots must number < 2^31, checked below)
   const uint32_t T = (uint32_t)std::max<uint64_t>(h->tile_bytes / row_bytes, 1);
   const uint32_t tiles = (rows_oth + T - 1) / T;
   if (tiles < 2 || tiles > 65534) return HPF_OK;
@@ -823,8 +825,10 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     // must be a function of the job, not of what else happens to be allocated.  If the allocations fail all the same the
     // side stays row-major and hpf_work_info.notes says so.
     size_t fr = 0, tot = 0;
-    const double resident = 5.0 * 8.0 * (double)h->ld * ((double)h->u.rows + (double)h->it.rows) + 20.0 * (double)nnz;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && resident + 40.0 * (double)nnz + (double)(1ull << 30) > 0.9 * (double)tot) {
+    const double by = h->u.val ? 1.0 : 0.0;
+    const double resident = 5.0 * 8.0 * (double)h->ld * ((double)h->u.rows + (double)h->it.rows)        // S, E, L, W + vectors of both sides
+                          + (double)nnz * (3.0 * (4.0 + by));                                          // CSR, CSC and the other side's tiled copy
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && resident + (double)nnz * (26.0 + 4.0 + by) + (double)(1ull << 30) > 0.9 * (double)tot) {
       h->notes |= (&s == &h->it ? 2u : 1u);
       return HPF_OK;
     }
@@ -918,6 +922,22 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     if ((rc = check_launch(h, "slot_fill_kernel"))) break;
     if ((rc = dalloc(h, &partial, (size_t)npartial * h->ld))) break;
     if (ngroup && (rc = dalloc(h, &partial2, (size_t)ngroup * h->ld))) break;
+    // the combine gives the rows with more than COMBINE_SPLIT partials a workgroup each: they go behind the others (a stable
+    // partition of the row-ordered list: a function of the matrix alone)
+    uint32_t nlong_wave = nlong;
+    if (nlong) {
+      std::vector<LongRow> lr(nlong), big;
+      HIPBRK(h, hipMemcpyAsync(lr.data(), longs, (size_t)nlong * sizeof(LongRow), hipMemcpyDeviceToHost, h->stream));
+      HIPBRK(h, hipStreamSynchronize(h->stream));
+      size_t w = 0;
+      for (const LongRow &x : lr) { if (x.nslots > COMBINE_SPLIT) big.push_back(x); else lr[w++] = x; }
+      if (!big.empty()) {
+        std::copy(big.begin(), big.end(), lr.begin() + (ptrdiff_t)w);
+        nlong_wave = (uint32_t)w;
+        HIPBRK(h, hipMemcpyAsync(longs, lr.data(), (size_t)nlong * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
+        HIPBRK(h, hipStreamSynchronize(h->stream));
+      }
+    }
 
     // ---- chunks: eight queues, one per XCD (workgroup b runs on XCD b % 8).  A tile goes to the queue
     // with the least work so far (its segments stay together and in order); with fewer than 32 tiles
@@ -1009,7 +1029,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     // ---- swap the side's work list
     dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows); dfree(s.partial); dfree(s.partial2);
     s.segs = segs; s.nseg = nseg; segs = nullptr;
-    s.longrows = longs; s.nlong = nlong; longs = nullptr;
+    s.longrows = longs; s.nlong = nlong; s.nlong_wave = nlong_wave; longs = nullptr;
     s.grouprows = groups; s.ngroup = ngroup; groups = nullptr;
     s.hugerows = huges; s.nhuge = nhuge; huges = nullptr;
     s.partial = partial; s.npartial = npartial; partial = nullptr;
@@ -1238,11 +1258,14 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   // the event separates the phi kernel from the combine that follows it
   if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
   auto combine = [&](const LongRow *rows, uint32_t nrows, const double *src, double *dst) {
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 65536)), dim3(256), (size_t)4 * h->ld * 8, h->stream,
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 16384)), dim3(256), 0, h->stream,
                        rows, nrows, src, dst, h->ld, h->flags);
   };
   if (own.ngroup) combine(own.grouprows, own.ngroup, own.partial, own.partial2);     // level 1 of the very long rows: partial -> partial2
-  if (own.nlong) combine(own.longrows, own.nlong, own.partial, own.S);
+  if (own.nlong_wave) combine(own.longrows, own.nlong_wave, own.partial, own.S);
+  if (own.nlong > own.nlong_wave)          // a tiled side's heavy rows (a partial per tile they meet): a workgroup each
+    hipLaunchKernelGGL(combine_partials_wg_kernel, dim3(std::min<uint32_t>(own.nlong - own.nlong_wave, 65536)), dim3(256), (size_t)4 * h->ld * 8,
+                       h->stream, own.longrows + own.nlong_wave, own.nlong - own.nlong_wave, own.partial, own.S, h->ld, h->flags);
   if (own.nhuge) combine(own.hugerows, own.nhuge, own.partial2, own.S);              // level 2: partial2 -> S
   return check_launch(h, "phi pass");
 }

@@ -682,72 +682,76 @@ __global__ __launch_bounds__(256) void gather_only_kernel(PhiArgs a, uint32_t *s
 }
 
 // long rows: S[row] = sum over its segments' partials, in segment order.
-// One wave per long row; a lane owns columns c and c + 64 at once and the slot
-// loop is unrolled 16-fold, so 32 independent loads are in flight per lane
-// (the longest row -- thousands of slots for a blockbuster item -- sets the
-// kernel's duration: it is a latency chain).  The adds stay in slot order.
-__device__ __forceinline__ void combine_columns(const double *partial, uint32_t first_slot, uint32_t nslots, uint32_t ld,
-                                                int lane, double (&s0)[1], double (&s1)[1], uint32_t c)
+// One wave per long row; a lane owns the column pairs (2 lane, 2 lane + 1) and (128 + 2 lane, ...) -- 16-byte loads
+// (round 4; ld is even and rows are 16-byte aligned) -- and the slot loop is unrolled 16-fold, so 32 independent loads
+// are in flight per lane (the longest row -- thousands of slots for a blockbuster item -- sets the kernel's duration:
+// it is a latency chain).  The adds of a column stay in slot order.
+struct ColQuad { double a0, a1, b0, b1; };
+__device__ __forceinline__ ColQuad combine_columns(const double *partial, uint32_t first_slot, uint32_t nslots, uint32_t ld, uint32_t c)
 {
-  const bool two = c + 64 < ld;
-  const double *p0 = partial + (size_t)first_slot * ld + c;
-  const double *p1 = two ? p0 + 64 : p0;
-  double a0 = 0.0, a1 = 0.0;
+  const bool two = c + 128 < ld;
+  const double2 *p0 = reinterpret_cast<const double2 *>(partial + (size_t)first_slot * ld + c);
+  const double2 *p1 = two ? p0 + 64 : p0;
+  const size_t st = ld / 2;                        // row stride in double2
+  ColQuad s = {0.0, 0.0, 0.0, 0.0};
   uint32_t q = 0;
   for (; q + 16 <= nslots; q += 16) {
-    double v0[16], v1[16];
+    double2 v0[16], v1[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * ld]; v1[j] = p1[(size_t)(q + j) * ld]; }
+    for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * st]; v1[j] = p1[(size_t)(q + j) * st]; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { a0 += v0[j]; a1 += v1[j]; }
+    for (int j = 0; j < 16; ++j) { s.a0 += v0[j].x; s.a1 += v0[j].y; s.b0 += v1[j].x; s.b1 += v1[j].y; }
   }
-  for (; q < nslots; ++q) { a0 += p0[(size_t)q * ld]; a1 += p1[(size_t)q * ld]; }
-  s0[0] = a0; s1[0] = a1;
+  for (; q < nslots; ++q) { const double2 u = p0[(size_t)q * st], w = p1[(size_t)q * st]; s.a0 += u.x; s.a1 += u.y; s.b0 += w.x; s.b1 += w.y; }
+  return s;
 }
 
-// A block takes four rows.  Rows of up to COMBINE_SPLIT partials: a wave each, as before.  Rows with more (round 4) --
-// a tiled side's heavy rows carry one partial per tile they meet, C2's items 184, C4's 176 -- are then worked on by
-// the whole workgroup, one after the other: the four waves take a quarter of the slots each (contiguous quarters, cut
-// by the slot count alone) and the four sums are added in wave order.  Which of the two a row gets, and hence the
-// order of its sum, is a function of its slot count: the same bits on every run.
-constexpr uint32_t COMBINE_SPLIT = 64;
 __global__ __launch_bounds__(256) void combine_partials_kernel(const LongRow *rows, uint32_t nrows,
                                                                const double *partial, double *S, uint32_t ld,
                                                                const uint32_t *flags)
 {
-  extern __shared__ double combine_part[];         // [4][ld]: the launch sizes it
   if (flags[0] & 6u) return;                       // the pass before it did not run (phi_pass_skips)
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t r = wave; r < nrows; r += nwaves) {
+    const LongRow lr = rows[r];
+    for (uint32_t c = 2 * lane; c < ld; c += 256) {
+      const ColQuad s = combine_columns(partial, lr.first_slot, lr.nslots, ld, c);
+      double2 *d = reinterpret_cast<double2 *>(S + (size_t)lr.row * ld + c);
+      d[0] = make_double2(s.a0, s.a1);
+      if (c + 128 < ld) d[64] = make_double2(s.b0, s.b1);
+    }
+  }
+}
+
+// The heavy rows of a TILED side carry one partial per tile they meet (C2's items 184, C4's 176): a single wave walking
+// that chain is a dozen round trips in a row.  Those rows -- more than COMBINE_SPLIT partials; build_tiled_side puts them
+// behind the others in the list -- get a WORKGROUP each (round 4): the four waves take a quarter of the slots each
+// (contiguous quarters, cut by the slot count alone) and the four sums are added in wave order.  Which kernel a row gets,
+// and hence the order of its sum, is a function of its slot count: the same bits on every run.
+constexpr uint32_t COMBINE_SPLIT = 64;
+__global__ __launch_bounds__(256) void combine_partials_wg_kernel(const LongRow *rows, uint32_t nrows,
+                                                                  const double *partial, double *S, uint32_t ld,
+                                                                  const uint32_t *flags)
+{
+  extern __shared__ double combine_part[];         // [4][ld]: the launch sizes it
+  if (flags[0] & 6u) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double *part0 = combine_part, *mine = combine_part + (size_t)wv * ld;
-  for (uint32_t r0 = blockIdx.x * 4; r0 < nrows; r0 += gridDim.x * 4) {
-    const uint32_t r = r0 + wv;
-    if (r < nrows) {
-      const LongRow lr = rows[r];
-      if (lr.nslots <= COMBINE_SPLIT)
-        for (uint32_t c = lane; c < ld; c += 128) {
-          double s0[1], s1[1];
-          combine_columns(partial, lr.first_slot, lr.nslots, ld, lane, s0, s1, c);
-          double *d = S + (size_t)lr.row * ld + c;
-          d[0] = s0[0];
-          if (c + 64 < ld) d[64] = s1[0];
-        }
+  double *mine = combine_part + (size_t)wv * ld;
+  for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const LongRow lr = rows[r];
+    const uint32_t per = (lr.nslots + 3) / 4;
+    const uint32_t q0 = min(per * wv, lr.nslots), q1 = min(q0 + per, lr.nslots);
+    for (uint32_t c = 2 * lane; c < ld; c += 256) {
+      const ColQuad s = combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, c);
+      mine[c] = s.a0; mine[c + 1] = s.a1;
+      if (c + 128 < ld) { mine[c + 128] = s.b0; mine[c + 129] = s.b1; }
     }
-    for (uint32_t k = 0; k < 4 && r0 + k < nrows; ++k) {           // block-uniform: every thread reads the same record
-      const LongRow lr = rows[r0 + k];
-      if (lr.nslots <= COMBINE_SPLIT) continue;
-      const uint32_t per = (lr.nslots + 3) / 4;
-      const uint32_t q0 = min(per * wv, lr.nslots), q1 = min(q0 + per, lr.nslots);
-      for (uint32_t c = lane; c < ld; c += 128) {
-        double s0[1], s1[1];
-        combine_columns(partial, lr.first_slot + q0, q1 - q0, ld, lane, s0, s1, c);
-        mine[c] = s0[0];
-        if (c + 64 < ld) mine[c + 64] = s1[0];
-      }
-      __syncthreads();
-      for (uint32_t c = threadIdx.x; c < ld; c += 256)
-        S[(size_t)lr.row * ld + c] = ((part0[c] + part0[ld + c]) + part0[2 * ld + c]) + part0[3 * ld + c];
-      __syncthreads();
-    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < ld; c += 256)
+      S[(size_t)lr.row * ld + c] = ((combine_part[c] + combine_part[ld + c]) + combine_part[2 * ld + c]) + combine_part[3 * ld + c];
+    __syncthreads();
   }
 }
 

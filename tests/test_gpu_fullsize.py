@@ -461,3 +461,35 @@ def test_more_than_2_31_nonzeros():
         seg = users[colptr[i]:colptr[i + 1]].astype(np.int64)
         assert np.all(np.diff(seg) > 0)
     D.close()
+
+
+def test_tiled_lists_past_2_32_nonzeros():
+    """a TILED side with more than 2^32 nonzeros (round 4: the guard that left such a side row-major is gone;
+    positions are 64-bit throughout, only the number of segments and partial slots has to stay below 2^31):
+    6M users x 300K items, 4.4e9 nonzeros, -binary-data, K = 4.  Mass per row and the values of a sample of
+    rows -- an index that wrapped at 2^32 would gather the wrong row or drop a run."""
+    import torch
+    from hgaprec_amd import synth
+    from tests import rowcheck
+    n, m, nnz, K = 6_000_000, 300_000, 4_400_000_000, 4
+    dev = torch.device("cuda", 0)
+    rowptr, col, val = synth.generate_device(n, m, nnz, 0.4, 0.7, seed=79, device=dev, binary=True)
+    torch.cuda.empty_cache()
+    assert int(rowptr[-1]) > 2**32 and val is None
+    cfg = dict(m=m, K=K, binary=True)
+    D = _device_model(cfg, n, rowptr, col, None, 0, n)
+    wi = D.work_info()
+    assert wi["tiles_item"] > 1 and wi["nnz"] == int(rowptr[-1]), wi
+    D.iterate(1)
+    ts = D.get_state_device("THETA_SHAPE", dev)
+    deg_u = _row_mass(rowptr, None)
+    assert float((((ts - 0.3).sum(1) - deg_u).abs() / deg_u.clamp(min=1.0)).max()) < 1e-11
+    del ts
+    bs = D.get_state_device("BETA_SHAPE", dev)
+    deg_i = rowcheck.item_degrees(col, m).to(torch.float64)
+    assert float((((bs - 0.3).sum(1) - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
+    del bs
+    r = rowcheck.check_handle(D, rowptr, col, None, n_users=300, n_items=40, seed=6)
+    print(">2^32 nnz, tiled:", wi, r)
+    assert r["ok"], r
+    D.close()
