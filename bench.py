@@ -23,7 +23,23 @@ hpf_upload_csr_device / hpf_set_state_device: no PCIe inside or before `value`).
           stored number; `rccl` says what the communicator saw.
   --weak  the round-1 mode: every rank owns a C2-sized shard (weak scaling).
 
-Rank 0 prints one JSON line.
+Rank 0 prints one JSON line.  Beside the contract's fields (round 4):
+
+  roofline        the dominant kernel against the HBM peak.  `frac` is the MEMORY-SIDE fraction:
+                  bytes that crossed from the fabric into the L2s per launch -- read from the PMC
+                  counters IN THIS RUN (two `rocprofv3 --kernel-trace --pmc` passes, FETCH_SIZE and
+                  WRITE_SIZE, over `bench.py --lean --steps 3` spawned after the timed region, with
+                  the guide's x 2 and its calibration on a kernel of known bytes in the same pass) --
+                  / the launch time of the timed region / 8 TB/s.  The contract's ALGORITHMIC bytes
+                  (every gathered row once per nonzero) / time stay beside it as `algorithmic_GBps`:
+                  cache-inclusive, may exceed the peak where tiles are served by the XCDs' L2s.
+  ms_per_step_median_hipevent   the median of the hipEvent-timed iterations beside the
+                  wall-clock mean `value` is computed from
+  self_check      mass conservation AND the values of a sample of owner rows (one more iteration,
+                  recomputed in fp64 from the exported Elog arrays: tests/rowcheck.py)
+  other_configs   C4 whole, what one of 8 GPUs holds of C3 and of C5: every BASELINE shape timed in
+                  the driver's own run (never part of `value`)
+  cpu_baseline    the CPU oracle on a slice of the same matrix, 1 thread (and all cores, for context)
 """
 from __future__ import annotations
 
@@ -675,7 +691,7 @@ def main():
             "work": {k: wi[k] for k in ("user_segments", "item_segments", "user_long_rows", "item_long_rows",
                                         "item_huge_rows", "phi_G", "phi_R", "phi_V", "sweep_G", "sweep_R", "ld", "w_layout",
                                         "tiles_user", "tiles_item", "tile_rows_user", "tile_rows_item",
-                                        "heavy_min_nnz_user", "heavy_min_nnz_item")},
+                                        "heavy_min_nnz_user", "heavy_min_nnz_item", "w_fallbacks", "notes")},
             "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
             # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user
@@ -783,7 +799,8 @@ def main():
         # the fabric into the XCDs' L2s per launch (PMC counters read in this run) / launch time / HBM peak.
         kern = "phi_item" if tm["phi_item_ms"] >= tm["phi_user_ms"] else "phi_user"
         kms = tm[kern + "_ms"]
-        kname = {0: "phi_pass_kernel", 2: "phi_pass_packed_kernel<codec_f48>", 3: "phi_pass_packed_kernel<codec_p59>"}.get(wi["w_layout"], "phi pass")
+        kname = {0: "phi_pass_kernel", 2: "phi_pass_packed_kernel<codec_f48>", 3: "phi_pass_packed_kernel<codec_p59>",
+                 4: "phi_pass_packed_kernel<codec_f64>"}.get(wi["w_layout"], "phi pass")
         kname, kbytes = f"{kname} ({kern} pass)", ab[kern]
         graph = kms == 0
         if graph:
@@ -869,7 +886,9 @@ def main():
             # the same pass with the arithmetic taken out: what the memory system needs for its gathers alone
             "gather_only_ms": (gather_only or {}).get(kern),
             "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
-            "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)"}.get(wi["w_layout"]),
+            "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)",
+                       4: "plain fp64 in 16-byte pieces (w_storage = 3, or after a fallback from the packed rows)"}.get(wi["w_layout"]),
+            "w_fallbacks": wi["w_fallbacks"],
             "tiles": {"phi_item": wi["tiles_item"], "phi_user": wi["tiles_user"],
                       "note": "0 = row-major pass; >0 = heavy rows regrouped by that many tiles of the gathered rows"},
             "per_kernel": per_kernel,

@@ -38,7 +38,7 @@ def counter_means(d):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src, dst = ROOT / "gpurun_out" / tag, ROOT / "profiles" / tag
     dst.mkdir(parents=True, exist_ok=True)
     for f in glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
@@ -167,7 +167,7 @@ def main():
         # the item pass where nothing it gathers is cache-resident (9 GB of user rows): algorithmic GB/s
         d3 = json.loads(c3f.read_text().strip().splitlines()[-1])
         pk = d3["roofline"]["per_kernel"]["phi_item"]
-        traffic["C3:phi_item_hbm_only_GBps"] = pk["GBps"]
+        traffic["C3:phi_item_hbm_only_GBps"] = pk.get("algorithmic_GBps", pk.get("GBps"))
     if traffic:
         traffic["kernels_sha"] = kernels_sha()
         traffic["measured"] = (f"profiles/{tag}/pmc_summary.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, bench.py --steps 3 "
