@@ -83,6 +83,22 @@ class Exchange:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
 
+    def allreduce_tail(self, ld: int):
+        """the last ld doubles alone: sum_u E[theta_u,:] (hpf_start_sums)"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.buf[-ld:], op=dist.ReduceOp.SUM, group=self.group)
+
+
+def start_sums(engine, exchange: Exchange | None):
+    """-bias -novb without -hier on several ranks (vb_bias()'s else-branch, hgaprec.cc:1276-1297): the first
+    item rate is built from sum_u E[theta] of the START state, summed over the ranks once.  The engine leaves
+    its part in the tail of the exchange buffer (hpf_start_sums); the tail alone is reduced.  Call after the
+    start state has been handed over and before the first iterate(); a no-op for every other mode."""
+    engine.start_sums()
+    if exchange is not None:
+        exchange.allreduce_tail(engine.work_info()["ld"])
+
 
 def iterate(engine, exchange: Exchange | None, n_iters: int = 1):
     """n_iters CAVI iterations of one rank of a sharded run (bench.py overlaps the

@@ -201,6 +201,10 @@ int  hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes);
  * -hier.  With n_ranks > 1 it needs hpf_comm_init and runs the overlapped
  * exchange (see below) itself; every rank must make the same call.
  * Asynchronous on the handle's stream.
+ * If a sweep meets an element the packed rows of W cannot hold (hpf_config.w_storage),
+ * the passes launched after it return at once; the next synchronising call moves the rows
+ * to plain doubles and runs what was skipped (hpf_work_info.w_fallbacks) -- results are
+ * those of a handle that never packed, only the timing of that call is not representative.
  * Launch-bound problems (nnz <= 4 Mi, or HPF_GRAPH=1; HPF_GRAPH=0 disables)
  * replay one captured iteration as a hipGraph: same kernels in the same
  * order, identical bits; such iterations report only iteration_ms in
