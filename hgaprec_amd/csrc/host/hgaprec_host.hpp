@@ -30,7 +30,7 @@ struct Env {
   // GPUs (one process each) and how the per-iteration all-reduce is carried
   int device = 0; bool device_set = false;
   bool no_tiles = false;                // -no-tiles: never tile the phi passes (hpf_config.tiling = 1)
-  bool plain_rows = false;              // -plain-rows: keep W in plain fp64 rows (for states with an Elog spread > 88 inside a row)
+  bool plain_rows = false;              // -plain-rows: W as plain doubles from the start (hpf_config.w_storage = 3; a packed handle moves there by itself when a state does not fit)
   int ngpus = 1;
   std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)
   bool single_allreduce = false;        // -single-allreduce: ONE all-reduce of [m x ld | ld] per iteration after the user half, as
