@@ -201,3 +201,48 @@ def test_tiled_list_longer_than_a_launch_holds(tile_env):
     deg_i = torch.bincount(col.to(torch.int64), minlength=m).to(torch.float64)
     assert float((((bs - 0.3).sum(1) - deg_i).abs() / deg_i.clamp(min=1.0)).max()) < 1e-11
     D.close()
+
+
+@pytest.mark.parametrize("where", ["before_the_first_pass", "in_a_sweep"])
+def test_fallback_from_packed_rows_cuts_the_tiled_lists_again(orc, tile_env, where):
+    """A tile holds a fixed number of BYTES of gathered rows: when the rows move from the packed form to plain
+    doubles (a state p59 cannot hold) the tiled lists are cut again for the longer rows, and
+    from there on the handle IS one that held plain doubles from the start: same layout, same lists, same kernels.
+    before_the_first_pass: the start state itself does not fit (an Elog spread of 120) -- every iteration runs on the
+    new lists and the run equals the w_storage = 3 run bit for bit.  in_a_sweep: the first user sweep cannot pack its
+    rows -- the first iteration's passes ran on the packed rows' lists, so the two runs differ by the order of that
+    iteration's sums (1e-13), and by nothing else."""
+    from hgaprec_amd.capi import Hpf
+    tile_env(HPF_TILE=2, HPF_TILE_BYTES=8192, HPF_TILE_RUN=2, HPF_TILE_SHARE=1)
+    n, m, K = 700, 500, 100
+    rowptr, col, val = make_problem(n, m, 30000, 23, heavy_user=True, heavy_item=True)
+    M = orc.Model(n, m, K, True, False, False)
+    M.set_csr(rowptr, col, val); M.initialize(23)
+    if where == "in_a_sweep":
+        be = M.state("BETA_E").copy()
+        be[:, 0] = 1e40                                   # the first user sweep's W is e^-97 of its row maximum in column 0
+        M.set_state("BETA_E", be)
+    else:
+        el = M.state("THETA_ELOG").copy()
+        el[:, 0] -= 120.0
+        M.set_state("THETA_ELOG", el)
+    runs = {}
+    for ws in (0, 3):
+        D = Hpf(n, m, K, hier=True, w_storage=ws)
+        D.upload_csr(rowptr, col, val)
+        wi0 = D.work_info()
+        copy_state(M, D, True, False)
+        D.iterate(3)
+        runs[ws] = ({w: D.get_state(w) for w in compare_states(True, False)}, wi0, D.work_info())
+        D.close()
+    M.iterate(3)
+    a0, a1 = runs[0][1], runs[0][2]
+    assert a0["w_layout"] == 3 and a1["w_layout"] == 4 and a1["w_fallbacks"] == 1
+    assert a0["tiles_item"] > 1 and a1["tiles_item"] > a0["tiles_item"]                # fewer of the longer rows per tile
+    assert (a1["tiles_user"], a1["tiles_item"], a1["tile_rows_item"]) == tuple(runs[3][2][k] for k in ("tiles_user", "tiles_item", "tile_rows_item"))
+    for w in compare_states(True, False):
+        if where == "before_the_first_pass":
+            assert np.array_equal(runs[0][0][w], runs[3][0][w]), w
+        else:
+            assert _err(w, runs[0][0][w], runs[3][0][w]) < 1e-11, w
+        assert _err(w, runs[0][0][w], M.state(w)) < RTOL, w
