@@ -79,7 +79,7 @@ struct hpf_handle {
   uint32_t K = 0, C = 0, ld = 0;
   bool w32 = false;                     // W stored as float (hpf_config.w_storage = 1)
   int wl = WL_PLAIN;                    // layout of W rows: plain, WL_P59 (lossless packing, default where it shortens
-                                        // the row) or WL_F48 (w_storage = 2); packed: phiR = 16-byte pieces per lane
+                                        // the row), WL_F48 (w_storage = 2) or WL_F64 (w_storage = 3, or after a fall-back); rows in pieces: phiR = 16-byte pieces per lane
   PackedRow pk = {0, 0, 0, 0, 0};
   PackedRow pks = {0, 0, 0, 0, 0};      // plain-fp64 rows in pieces for the same columns (codec_f64): what the rows become when p59
                                         // cannot hold a state (recover_flush)
