@@ -102,7 +102,7 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
     }
 
 
-def pmc_passes(argv_workload, n_rows_big, ld, tmo=600):
+def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
     slots") over `bench.py --lean --steps 3 --warmup 1` of the same workload, spawned after the
