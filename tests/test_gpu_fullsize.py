@@ -130,6 +130,15 @@ def test_c2_sampled_rows_and_a_damaged_index(c2):
     D.debug_poke_index(1, nnz - 1, old)
     good = rowcheck.check_handle(D, rp, c, v, users=[0, 1], items=[owner, 0])
     assert good["ok"], good
+    # the same on the row-major user side: the first nonzero of user 12345 pointed at another item
+    pos = int(rowptr[12345])
+    old_u, owner_u = D.debug_poke_index(0, pos, 0)
+    assert owner_u == 12345 and old_u == int(col[pos])
+    D.debug_poke_index(0, pos, (old_u + 4321) % cfg["m"])
+    bad = rowcheck.check_handle(D, rp, c, v, users=[12345, 7], items=[0, 1])
+    assert not bad["ok"] and bad["worst_row"] == ["user", 12345], bad
+    D.debug_poke_index(0, pos, old_u)
+    assert rowcheck.check_handle(D, rp, c, v, users=[12345, 7], items=[0, 1])["ok"]
     D.close()
 
 
