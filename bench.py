@@ -102,6 +102,29 @@ def cpu_baseline(cfg, rowptr, col, val, target_nnz=4_000_000):
     }
 
 
+def parse_counter_csvs(directory, ctr):
+    """rocprofv3 --pmc output under `directory` -> ({side: [counter value per launch of that phi pass]},
+    [counter values of materialize_es_kernel launches]); side 0 = user-major, 1 = item-major: the last template
+    argument of the pass kernels (phi_pass_kernel<..., SIDE>, phi_pass_packed_kernel<..., SIDE>)"""
+    import csv
+    import glob
+    import re
+    vals = {0: [], 1: []}
+    calv = []
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != ctr:
+                continue
+            name = row["Kernel_Name"]
+            if "phi_pass" in name:
+                mt = re.search(r",\s*(\d)>\(", name)
+                if mt:
+                    vals[int(mt.group(1))].append(float(row["Counter_Value"]))
+            elif "materialize_es_kernel" in name:
+                calv.append(float(row["Counter_Value"]))
+    return vals, calv
+
+
 def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
@@ -134,19 +157,7 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=tmo)
             if r.returncode != 0:
                 return None, None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
-            vals = {0: [], 1: []}
-            calv = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] != ctr:
-                        continue
-                    name = row["Kernel_Name"]
-                    if "phi_pass" in name:
-                        mt = re.search(r",\s*(\d)>\(", name)
-                        if mt:
-                            vals[int(mt.group(1))].append(float(row["Counter_Value"]))
-                    elif "materialize_es_kernel" in name:
-                        calv.append(float(row["Counter_Value"]))
+            vals, calv = parse_counter_csvs(d, ctr)
             for sd in (0, 1):
                 v = vals[sd][1:] if len(vals[sd]) > 1 else vals[sd]        # the first launch is the warm-up iteration
                 if v:
