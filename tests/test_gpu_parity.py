@@ -623,15 +623,18 @@ def test_lossless_packed_rows_and_plain_rows_both_match_the_oracle(orc, monkeypa
     assert abs(D.elbo() - M.elbo()) <= 1e-10 * abs(M.elbo())
 
 
+@pytest.mark.parametrize("ws", [0, 3], ids=["p59", "plain_doubles"])
 @pytest.mark.parametrize("K", [13, 30, 64, 96, 128, 150, 256, 300, 500, 700])
-def test_every_packed_kernel_shape_matches_the_oracle(orc, monkeypatch, K):
+def test_every_packed_kernel_shape_matches_the_oracle(orc, monkeypatch, K, ws):
     """a K sweep with the packing forced: lane groups of 8 to 64 lanes, 1 to 8 pieces per lane, sweep
-    shapes with and without masked columns in the last slot -- three sweeps each against the oracle"""
+    shapes with and without masked columns in the last slot (built in registers, or in LDS for 64-lane
+    groups) -- and the same shapes holding plain doubles (w_storage = 3: up to 9 pieces per lane, what a
+    packed handle falls back to) -- three sweeps each against the oracle"""
     monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
     monkeypatch.setenv("HPF_W_PACK", "1")
-    M, D = _run_pair(orc, 150, 120, K, 2500, True, K % 2 == 0, False, 3, seed=K)
+    M, D = _run_pair(orc, 150, 120, K, 2500, True, K % 2 == 0, False, 3, seed=K, w_storage=ws)
     wi = D.work_info()
-    assert wi["w_layout"] == 3 and wi["ld"] >= K
+    assert wi["w_layout"] == (3 if ws == 0 else 4) and wi["ld"] >= K
     M.iterate(3); D.iterate(3)
     for w in compare_states(True, K % 2 == 0):
         e = rel_err(D.get_state(w), M.state(w))
