@@ -13,6 +13,7 @@
 #include <sstream>
 #include <thread>
 #include <functional>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -230,16 +231,44 @@ struct Tok {
 };
 }  // namespace
 
-int Ratings::read_generic(FILE *f, HeldOut *out)
-{
-  Tok tk(f);
-  uint32_t mid = 0, uid = 0, rating = 0;        // persist across lines like the reference's locals
-  // capacity for this pass: ratings.cc:35-36 shrinks env.n / env.m to the
-  // registered counts once the training file has been read
-  const uint32_t lim_n = out ? n : cap_n, lim_m = out ? m : cap_m;
-  bool first = true;
+// One record of a ratings file, in the reference's order of tests (ratings.cc:77-111).  The two "last
+// successful lookup" pairs only save hash probes (files are usually grouped by user).
+struct Ratings::Consumer {
+  Ratings &r; HeldOut *out; uint32_t lim_n, lim_m;
   bool have_last_u = false, have_last_m = false;
   uint32_t last_uid = 0, last_us = 0, last_mid = 0, last_ms = 0;
+  // capacity for this pass: ratings.cc:35-36 shrinks env.n / env.m to the
+  // registered counts once the training file has been read
+  Consumer(Ratings &rr, HeldOut *o) : r(rr), out(o), lim_n(o ? rr.n : rr.cap_n), lim_m(o ? rr.m : rr.cap_m) {}
+  void take(uint32_t uid, uint32_t mid, uint32_t rating) {
+    uint32_t us = 0, ms = 0;
+    bool hasu, hasm;
+    if (have_last_u && uid == last_uid) { hasu = true; us = last_us; }
+    else if ((hasu = r.user2seq.find(uid, &us))) { have_last_u = true; last_uid = uid; last_us = us; }
+    if (have_last_m && mid == last_mid) { hasm = true; ms = last_ms; }
+    else if ((hasm = r.item2seq.find(mid, &ms))) { have_last_m = true; last_mid = mid; last_ms = ms; }
+    if ((!hasu && r.n >= lim_n) || (!hasm && r.m >= lim_m)) return;
+    if (r.input_rating_class(rating) == 0) return;
+    if (!hasu) { us = r.n; r.user2seq.put(uid, us); r.seq2user.push_back(uid); r.n++; }     // ratings.hh:117-133
+    if (!hasm) { ms = r.m; r.item2seq.put(mid, ms); r.seq2item.push_back(mid); r.m++; }     // ratings.hh:135-151
+    if (!out) {
+      r.nratings++;
+      r.tr_u_.push_back(us); r.tr_i_.push_back(ms); r.tr_y_.push_back(rating);
+    } else {
+      out->u.push_back(us); out->i.push_back(ms);
+      out->y.push_back(r.binary ? 1 : (int32_t)rating);
+    }
+  }
+};
+
+int Ratings::read_generic(FILE *f, HeldOut *out)
+{
+  const int fast = read_generic_parallel(f, out);   // 0: done; 1: this file takes the token-by-token reader
+  if (fast <= 0) return fast;
+  Tok tk(f);
+  uint32_t mid = 0, uid = 0, rating = 0;        // persist across lines like the reference's locals
+  Consumer c(*this, out);
+  bool first = true;
   while (true) {
     // while (!feof(f)) { if (fscanf(...) < 0) exit(-1); ... }
     if (!first && tk.at_eof()) break;           // the trailing "\n" directive ate the whitespace
@@ -255,23 +284,178 @@ int Ratings::read_generic(FILE *f, HeldOut *out)
       fprintf(stderr, "error: malformed line in ratings file\n");
       return -2;
     }
-    // files are usually grouped by user: remember the last successful lookup
-    uint32_t us = 0, ms = 0;
-    bool hasu, hasm;
-    if (have_last_u && uid == last_uid) { hasu = true; us = last_us; }
-    else if ((hasu = user2seq.find(uid, &us))) { have_last_u = true; last_uid = uid; last_us = us; }
-    if (have_last_m && mid == last_mid) { hasm = true; ms = last_ms; }
-    else if ((hasm = item2seq.find(mid, &ms))) { have_last_m = true; last_mid = mid; last_ms = ms; }
-    if ((!hasu && n >= lim_n) || (!hasm && m >= lim_m)) continue;
-    if (input_rating_class(rating) == 0) continue;
-    if (!hasu) { us = n; user2seq.put(uid, us); seq2user.push_back(uid); n++; }     // ratings.hh:117-133
-    if (!hasm) { ms = m; item2seq.put(mid, ms); seq2item.push_back(mid); m++; }     // ratings.hh:135-151
-    if (!out) {
-      nratings++;
-      tr_u_.push_back(us); tr_i_.push_back(ms); tr_y_.push_back(rating);
-    } else {
-      out->u.push_back(us); out->i.push_back(ms);
-      out->y.push_back(binary ? 1 : (int32_t)rating);
+    c.take(uid, mid, rating);
+  }
+  return 0;
+}
+
+// ---- the same reader on all host threads ------------------------------------
+// A ratings file of 10^8..10^9 lines is seconds to minutes of single-thread parsing in front of iterations
+// that take milliseconds.  For a WELL-FORMED file -- nothing but decimal digits and white space, a multiple
+// of three tokens -- the result of the loop above can be produced in pieces:
+//   1. the text is cut at white space into one piece per thread; the pieces count their tokens and refuse
+//      anything that is not a digit or white space; a second pass parses the tokens into one array;
+//   2. records (token triples) are dealt to the threads in file order; each notes, in order, the user and
+//      item ids it sees for the first time among records whose rating class is not 0;
+//   3. one thread merges those lists piece by piece: an id's sequence number is its rank among first
+//      appearances -- what the loop above assigns as long as neither capacity (-n / -m) runs out.  If one
+//      would, the maps are reset and the records go through Consumer::take one by one (the tests on
+//      capacity couple the two sides, ratings.cc:84-85);
+//   4. the threads translate their records through the finished maps into their place of the output.
+// Held-out files never register ids (their capacities are the registered counts): steps 2-3 fall away.
+// Anything else -- a sign, a letter, a token count that is no multiple of three, a small file, one thread --
+// returns 1 and the token-by-token reader above takes the file with the reference's behaviour for it.
+namespace {
+inline bool is_ws(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }   // isspace, "C" locale
+struct LocalIds {          // ids in order of first appearance inside one piece
+  std::vector<uint64_t> slots; std::vector<uint32_t> order; uint32_t mask;
+  LocalIds() : slots(1024, 0), mask(1023) {}
+  void note(uint32_t key) {
+    for (uint32_t i = hash32(key) & mask;; i = (i + 1) & mask) {
+      const uint64_t e = slots[i];
+      if (!e) { slots[i] = ((uint64_t)key << 1) | 1u; order.push_back(key); if (order.size() * 2 > slots.size()) grow(); return; }
+      if ((uint32_t)(e >> 1) == key) return;
+    }
+  }
+  void grow() {
+    std::vector<uint64_t> old(std::move(slots));
+    slots.assign(old.size() * 2, 0); mask = (uint32_t)slots.size() - 1;
+    for (uint64_t e : old) if (e) { uint32_t i = hash32((uint32_t)(e >> 1)) & mask; while (slots[i]) i = (i + 1) & mask; slots[i] = e; }
+  }
+};
+template <typename F> void on_threads(unsigned nt, F fn)
+{
+  if (nt == 1) { fn(0u); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
+  for (auto &x : th) x.join();
+}
+}  // namespace
+
+int Ratings::read_generic_parallel(FILE *f, HeldOut *out)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = getenv("HGAPREC_READ_THREADS")) nt = (unsigned)atoi(e);
+  nt = std::min(nt, 64u);
+  size_t min_bytes = (size_t)8 << 20;
+  if (const char *e = getenv("HGAPREC_READ_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 0);
+  struct stat st;
+  if (nt < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < std::max<size_t>(min_bytes, 1)) return 1;
+  const size_t size = (size_t)st.st_size;
+  void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+  if (map == MAP_FAILED) return 1;
+  const unsigned char *d = (const unsigned char *)map;
+  struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, size};
+  nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, size / 64 + 1));
+
+  // 1. pieces of text that start behind white space; tokens per piece; only digits and white space
+  std::vector<size_t> cut(nt + 1, size);
+  cut[0] = 0;
+  for (unsigned t = 1; t < nt; ++t) {
+    size_t p = std::max(cut[t - 1], size / nt * t);
+    while (p < size && p > 0 && !is_ws(d[p - 1])) ++p;
+    cut[t] = p;
+  }
+  std::vector<uint64_t> ntok(nt + 1, 0);
+  std::vector<char> dirty(nt, 0);
+  on_threads(nt, [&](unsigned t) {
+    uint64_t cnt = 0; bool in = false, bad = false;
+    for (size_t p = cut[t]; p < cut[t + 1]; ++p) {
+      const unsigned char c = d[p];
+      if (c >= '0' && c <= '9') { cnt += !in; in = true; }
+      else if (is_ws(c)) in = false;
+      else { bad = true; break; }
+    }
+    ntok[t + 1] = cnt; dirty[t] = bad;
+  });
+  for (unsigned t = 0; t < nt; ++t) { if (dirty[t]) return 1; ntok[t + 1] += ntok[t]; }
+  const uint64_t N = ntok[nt];
+  if (N == 0 || N % 3 != 0) return 1;
+  std::vector<uint32_t> tok(N);
+  on_threads(nt, [&](unsigned t) {
+    uint32_t *o = tok.data() + ntok[t];
+    const unsigned char *p = d + cut[t], *e = d + cut[t + 1];
+    while (p < e) {
+      while (p < e && is_ws(*p)) ++p;
+      if (p == e) break;
+      uint64_t v = 0;
+      for (; p < e && *p >= '0' && *p <= '9'; ++p) { v = v * 10 + (uint64_t)(*p - '0'); if (v > 0xffffffffffffull) v &= 0xffffffffull; }   // as Tok::next_u32
+      *o++ = (uint32_t)v;
+    }
+  });
+
+  const uint64_t R = N / 3;
+  nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, R / 1024 + 1));
+  auto rec0 = [&](unsigned t) { return R / nt * t + std::min<uint64_t>(t, R % nt); };
+  std::vector<uint64_t> kept(nt + 1, 0);
+  if (!out) {
+    // 2. first appearances per piece, among the records that count
+    std::vector<LocalIds> lu(nt), li(nt);
+    on_threads(nt, [&](unsigned t) {
+      uint64_t cnt = 0; bool have = false; uint32_t last = 0;
+      for (uint64_t r = rec0(t), e = rec0(t + 1); r < e; ++r) {
+        if (input_rating_class(tok[3 * r + 2]) == 0) continue;
+        const uint32_t uid = tok[3 * r], mid = tok[3 * r + 1];
+        if (!have || uid != last) { lu[t].note(uid); have = true; last = uid; }
+        li[t].note(mid);
+        ++cnt;
+      }
+      kept[t + 1] = cnt;
+    });
+    // 3. merge in file order
+    bool overflow = false;
+    uint32_t v;
+    for (unsigned t = 0; t < nt && !overflow; ++t) {
+      for (uint32_t uid : lu[t].order) {
+        if (user2seq.find(uid, &v)) continue;
+        if (n >= cap_n) { overflow = true; break; }
+        user2seq.put(uid, n); seq2user.push_back(uid); n++;
+      }
+      for (uint32_t mid : li[t].order) {
+        if (overflow) break;
+        if (item2seq.find(mid, &v)) continue;
+        if (m >= cap_m) { overflow = true; break; }
+        item2seq.put(mid, m); seq2item.push_back(mid); m++;
+      }
+    }
+    if (overflow) {          // a capacity binds: which records survive depends on the order of BOTH sides
+      user2seq = IdMap(); item2seq = IdMap(); seq2user.clear(); seq2item.clear(); n = m = 0; nratings = 0;
+      Consumer c(*this, nullptr);
+      for (uint64_t r = 0; r < R; ++r) c.take(tok[3 * r], tok[3 * r + 1], tok[3 * r + 2]);
+      return 0;
+    }
+    for (unsigned t = 0; t < nt; ++t) kept[t + 1] += kept[t];
+    nratings = kept[nt];
+    tr_u_.resize(nratings); tr_i_.resize(nratings); tr_y_.resize(nratings);
+    // 4. every record that counts, through the finished maps
+    on_threads(nt, [&](unsigned t) {
+      uint64_t o = kept[t]; bool have = false; uint32_t last = 0, us = 0, ms = 0;
+      for (uint64_t r = rec0(t), e = rec0(t + 1); r < e; ++r) {
+        const uint32_t y = tok[3 * r + 2];
+        if (input_rating_class(y) == 0) continue;
+        const uint32_t uid = tok[3 * r];
+        if (!have || uid != last) { user2seq.find(uid, &us); have = true; last = uid; }
+        item2seq.find(tok[3 * r + 1], &ms);
+        tr_u_[o] = us; tr_i_[o] = ms; tr_y_[o] = y; ++o;
+      }
+    });
+    return 0;
+  }
+  // held-out file: a record counts when both ids are registered and its rating class is not 0
+  for (int pass = 0; pass < 2; ++pass) {
+    on_threads(nt, [&](unsigned t) {
+      uint64_t o = kept[t], cnt = 0; uint32_t us = 0, ms = 0;
+      for (uint64_t r = rec0(t), e = rec0(t + 1); r < e; ++r) {
+        const uint32_t y = tok[3 * r + 2];
+        if (!user2seq.find(tok[3 * r], &us) || !item2seq.find(tok[3 * r + 1], &ms) || input_rating_class(y) == 0) continue;
+        if (pass) { out->u[o] = us; out->i[o] = ms; out->y[o] = binary ? 1 : (int32_t)y; ++o; }
+        ++cnt;
+      }
+      if (!pass) kept[t + 1] = cnt;
+    });
+    if (!pass) {
+      for (unsigned t = 0; t < nt; ++t) kept[t + 1] += kept[t];
+      out->u.resize(kept[nt]); out->i.resize(kept[nt]); out->y.resize(kept[nt]);
     }
   }
   return 0;
@@ -290,35 +474,60 @@ int Ratings::read_train(const std::string &path)
   // LAST one written to the per-user std::map<item,uint8_t> (ratings.cc:96-103)
   const uint64_t nnz = tr_u_.size();
   rowptr.assign((size_t)n + 1, 0);
-  for (uint64_t j = 0; j < nnz; ++j) rowptr[(size_t)tr_u_[j] + 1]++;
-  for (uint32_t u = 0; u < n; ++u) rowptr[u + 1] += rowptr[u];
   col.resize(nnz); val.resize(nnz);
-  {
-    std::vector<int64_t> next(rowptr.begin(), rowptr.end() - 1);
+  // A stable counting sort by user.  On several threads every thread owns a range of users and walks ALL
+  // records in file order for them (sequential reads, no shared counter): inside a row the file order,
+  // whatever the number of threads.
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = getenv("HGAPREC_READ_THREADS")) nt = (unsigned)atoi(e);
+  nt = std::max(1u, std::min(nt, 32u));
+  if (nnz < ((uint64_t)1 << 22) && !getenv("HGAPREC_READ_PARALLEL_MIN")) nt = 1;
+  nt = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>(nt, n));
+  std::vector<uint32_t> ucut(nt + 1, n);
+  for (unsigned t = 0; t <= nt; ++t) ucut[t] = (uint32_t)((uint64_t)n * t / nt);
+  const uint32_t *tu = tr_u_.data();
+  on_threads(nt, [&](unsigned t) {
+    const uint32_t lo = ucut[t], span = ucut[t + 1] - lo;
+    int64_t *cnt = rowptr.data() + 1;
+    for (uint64_t j = 0; j < nnz; ++j) { const uint32_t u = tu[j] - lo; if (u < span) cnt[u + lo]++; }
+  });
+  for (uint32_t u = 0; u < n; ++u) rowptr[u + 1] += rowptr[u];
+  for (unsigned t = 1; t < nt; ++t)            // ranges of about equal numbers of ratings from here on
+    ucut[t] = (uint32_t)(std::lower_bound(rowptr.begin(), rowptr.end(), (int64_t)(nnz / nt * t)) - rowptr.begin());
+  for (unsigned t = 1; t <= nt; ++t) ucut[t] = std::max(ucut[t], ucut[t - 1]);
+  ucut[nt] = n;
+  on_threads(nt, [&](unsigned t) {
+    const uint32_t lo = ucut[t], span = ucut[t + 1] - lo;
+    if (!span) return;
+    std::vector<int64_t> next(rowptr.begin() + lo, rowptr.begin() + lo + span);
     for (uint64_t j = 0; j < nnz; ++j) {
-      const int64_t p = next[tr_u_[j]]++;
+      const uint32_t u = tu[j] - lo;
+      if (u >= span) continue;
+      const int64_t p = next[u]++;
       col[(size_t)p] = tr_i_[j];
       val[(size_t)p] = binary ? 1 : (uint8_t)tr_y_[j];       // yval_t = uint8_t (env.hh:20)
     }
-  }
-  // rows with a repeated item are rare: find them with a "last user that listed
-  // this item" stamp (linear), and only those rows take the sort-based fix-up
-  std::vector<uint32_t> perm, stamp(m, 0xffffffffu);
-  for (uint32_t u = 0; u < n; ++u) {
-    const int64_t a = rowptr[u], b = rowptr[u + 1];
-    bool dup = false;
-    for (int64_t j = a; j < b; ++j) { if (stamp[col[(size_t)j]] == u) dup = true; stamp[col[(size_t)j]] = u; }
-    if (!dup) continue;
-    perm.resize((size_t)(b - a));
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return col[a + x] < col[a + y]; });
-    for (size_t s = 0; s < perm.size();) {
-      size_t e = s;
-      while (e + 1 < perm.size() && col[a + perm[e + 1]] == col[a + perm[s]]) ++e;
-      if (e > s) { const uint8_t last = val[a + perm[e]]; for (size_t t = s; t <= e; ++t) val[a + perm[t]] = last; }
-      s = e + 1;
+    // rows with a repeated item are rare: find them with a "last user that listed
+    // this item" stamp (linear), and only those rows take the sort-based fix-up:
+    // the rating used for every copy of a duplicated (u,i) is the LAST one written
+    // to the per-user std::map<item,uint8_t> (ratings.cc:96-103)
+    std::vector<uint32_t> perm, stamp(m, 0xffffffffu);
+    for (uint32_t u = lo; u < lo + span; ++u) {
+      const int64_t a = rowptr[u], b = rowptr[u + 1];
+      bool dup = false;
+      for (int64_t j = a; j < b; ++j) { if (stamp[col[(size_t)j]] == u) dup = true; stamp[col[(size_t)j]] = u; }
+      if (!dup) continue;
+      perm.resize((size_t)(b - a));
+      std::iota(perm.begin(), perm.end(), 0u);
+      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return col[a + x] < col[a + y]; });
+      for (size_t s2 = 0; s2 < perm.size();) {
+        size_t e = s2;
+        while (e + 1 < perm.size() && col[a + perm[e + 1]] == col[a + perm[s2]]) ++e;
+        if (e > s2) { const uint8_t last = val[a + perm[e]]; for (size_t q = s2; q <= e; ++q) val[a + perm[q]] = last; }
+        s2 = e + 1;
+      }
     }
-  }
+  });
   std::vector<uint32_t>().swap(tr_u_); std::vector<uint32_t>().swap(tr_i_); std::vector<uint32_t>().swap(tr_y_);
   return 0;
 }
@@ -587,7 +796,27 @@ void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate, uint
     for (uint32_t i = 0; i < hi - lo; ++i) for (uint32_t j = 0; j < k; ++j) rate[(size_t)i * k + j] = b0[j];
   }
 }
-// initialize_exp (gpbase.hh:324-340 / 700-715): fresh rate draw per element
+// elements [0, cnt) in equal pieces on the host's threads (capped at 32; HGAPREC_SAVE_THREADS overrides); every
+// element is computed by the same scalar code whichever thread takes it, so the result does not depend on the count
+template <typename F>
+void parallel_pieces(size_t cnt, F fn)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = getenv("HGAPREC_SAVE_THREADS")) nt = (unsigned)atoi(e);
+  nt = std::max(1u, std::min(nt, 32u));
+  if (cnt < ((size_t)1 << 16)) nt = 1;
+  if (nt == 1) { fn((size_t)0, cnt); return; }
+  std::vector<std::thread> th;
+  const size_t piece = (cnt + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t a = std::min(cnt, (size_t)t * piece), b = std::min(cnt, a + piece);
+    if (a < b) th.emplace_back(fn, a, b);
+  }
+  for (auto &x : th) x.join();
+}
+// initialize_exp (gpbase.hh:324-340 / 700-715): fresh rate draw per element.  The draws are taken in the
+// reference's order by one thread; digamma and log of the kept rows -- nine tenths of the time of a start
+// state (C2: 1.1e8 elements) -- go to the host's threads afterwards.
 void gp_initialize_exp(Mt19937 &r, uint32_t rows, uint32_t k, uint32_t lo, uint32_t hi,
                        const std::vector<double> &shape, std::vector<double> &E, std::vector<double> &Elog)
 {
@@ -595,12 +824,17 @@ void gp_initialize_exp(Mt19937 &r, uint32_t rows, uint32_t k, uint32_t lo, uint3
   for (uint32_t i = 0; i < rows; ++i)
     for (uint32_t j = 0; j < k; ++j) {
       const double b = RPRIOR + 0.1 * r.uniform();
-      if (i >= lo && i < hi) {
-        const size_t e = (size_t)(i - lo) * k + j;
-        E[e] = shape[e] / b;
-        Elog[e] = digamma(shape[e]) - std::log(b);
-      }
+      if (i >= lo && i < hi) E[(size_t)(i - lo) * k + j] = b;          // the rate for now
     }
+  const double *sh = shape.data();
+  double *pe = E.data(), *pl = Elog.data();
+  parallel_pieces(shape.size(), [sh, pe, pl](size_t a, size_t b2) {
+    for (size_t e = a; e < b2; ++e) {
+      const double b = pe[e];
+      pe[e] = sh[e] / b;
+      pl[e] = digamma(sh[e]) - std::log(b);
+    }
+  });
 }
 // initialize2(v) + compute_expectations (gpbase.hh:310-322,939-949; 248-262,912-925)
 void gp_initialize2(Mt19937 &r, uint32_t rows, double v, uint32_t lo, uint32_t hi, std::vector<double> &shape,

@@ -121,6 +121,8 @@ struct Ratings {
 
  private:
   int read_generic(FILE *f, HeldOut *out);
+  int read_generic_parallel(FILE *f, HeldOut *out);   // 0 done, 1 not for this file (small, not well-formed, one thread)
+  struct Consumer;
   uint32_t input_rating_class(uint32_t v) const;
   std::vector<uint32_t> tr_u_, tr_i_, tr_y_;   // training triples in file order
 };

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cerrno>
 #include <csignal>
 #include <cstdlib>
@@ -35,6 +36,31 @@ static volatile sig_atomic_t g_save_state_now = 0;
 static void term_handler(int) { g_save_state_now = 1; }   // main.cc:19-30
 
 namespace {
+
+// HPF_CLI_TIMING=1: wall seconds of each phase of the run on stderr (tools/cli_walltime.py reads them)
+struct PhaseClock {
+  bool on = getenv("HPF_CLI_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double acc_iter = 0, acc_report = 0, acc_part[5] = {0, 0, 0, 0, 0};   // parts: likelihood, save_model, precision, itemrank, on stop
+  std::chrono::steady_clock::time_point p0;
+  void part_begin() { p0 = std::chrono::steady_clock::now(); }
+  void part_end(int j) { acc_part[j] += std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count(); }
+  double lap() {
+    const auto t1 = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+    return s;
+  }
+  void mark(const char *what) { const double s = lap(); if (on) fprintf(stderr, "[timing] %-28s %9.3f s\n", what, s); }
+  void totals(uint32_t iterations) {
+    if (!on) return;
+    fprintf(stderr, "[timing] %-28s %9.3f s\n[timing] %-28s %9.3f s\n[timing] %-28s %9u\n", "iterations (hpf_iterate)", acc_iter,
+            "report steps + saves", acc_report, "iterations run", iterations);
+    const char *nm[5] = {"  held-out likelihood", "  save_model", "  compute_precision", "  compute_itemrank", "  on stop (save + ranking)"};
+    for (int j = 0; j < 5; ++j) fprintf(stderr, "[timing] %-28s %9.3f s\n", nm[j], acc_part[j]);
+  }
+};
+PhaseClock g_clock;
 
 struct Driver {
   Env &env; Ratings &rt; Comm &comm; hpf_handle *h = nullptr;
@@ -101,6 +127,7 @@ struct Driver {
       }
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
+    g_clock.lap();
     if (!rt.heldout_loaded) {                     // else: came with the -cache image
       int rc = rt.read_heldout(env.datfname + "/validation.tsv", &rt.validation);
       assert(rc != -1);
@@ -129,6 +156,7 @@ struct Driver {
       }
     }
 
+    g_clock.mark("validation.tsv + test.tsv");
     // this rank's contiguous user range, balanced on the nnz prefix sum
     const auto parts = partition_users(rt.rowptr, comm.world);
     lo = parts[comm.rank].first; hi = parts[comm.rank].second;
@@ -149,8 +177,10 @@ struct Driver {
     std::vector<int64_t> rp(rt.rowptr.begin() + lo, rt.rowptr.begin() + hi + 1);
     const int64_t base = rp[0];
     for (auto &v : rp) v -= base;
+    g_clock.mark("hpf_create (HIP start-up)");
     rc = hpf_upload_csr(h, rp.data(), rt.col.data() + base, env.binary_data ? nullptr : rt.val.data() + base);
     if (rc) die("hpf_upload_csr", rc);
+    g_clock.mark("hpf_upload_csr");
     {
       hpf_work_info wi;
       if (root() && hpf_get_work_info(h, &wi) == HPF_OK)      // infer.log: how the device side laid the work out
@@ -173,7 +203,9 @@ struct Driver {
   void initialize() {
     rng = make_rng(env.seed);
     GammaState s;
+    g_clock.lap();
     initialize_state(rng, n, m, k, env.hier, env.bias, &s, lo, hi);
+    g_clock.mark("start state (MT19937, host)");
     auto put = [&](hpf_state w, const std::vector<double> &v) {
       int rc = hpf_set_state(h, w, v.data(), v.size());
       if (rc) die("hpf_set_state", rc);
@@ -190,6 +222,7 @@ struct Driver {
       put(HPF_UBIAS_SHAPE, s.ubias_shape); put(HPF_UBIAS_E, s.ubias_E); put(HPF_UBIAS_ELOG, s.ubias_Elog);
       put(HPF_IBIAS_SHAPE, s.ibias_shape); put(HPF_IBIAS_E, s.ibias_E); put(HPF_IBIAS_ELOG, s.ibias_Elog);
     }
+    g_clock.mark("hpf_set_state");
   }
 
   // -bias -novb without -hier on several ranks (vb_bias()'s else-branch, hgaprec.cc:1276-1297): the first
@@ -506,12 +539,14 @@ struct Driver {
       fprintf(f, "%d\t%d\t%.5f\t%d\n", iter, duration(), a, why);
       close_or_die(f, env.file_str("/max.txt"));
     }
-    if (st) { do_on_stop(); return true; }
+    if (st) { g_clock.part_begin(); do_on_stop(); g_clock.part_end(4); return true; }
     return false;
   }
 
   void finish(int code) {
+    g_clock.lap();
     if (h) { hpf_synchronize(h); hpf_destroy(h); h = nullptr; }
+    if (root()) { g_clock.totals(iter); g_clock.mark("hpf_destroy"); }
     comm.barrier();
     comm.close_all();
     exit(code);
@@ -582,15 +617,23 @@ struct Driver {
     start_sums();
     while (1) {
       if (env.hier && iter > env.max_iterations) finish(0);
+      g_clock.lap();
       iterate();
+      if (g_clock.on) hpf_synchronize(h);
+      g_clock.acc_iter += g_clock.lap();
       if (root()) { printf("\r iteration %d", iter); fflush(stdout); }
       if (iter % env.rfreq == 0) {
+        g_clock.part_begin();
         if (compute_likelihood(true)) finish(0);
         note_fallback();
         compute_likelihood(false);
+        g_clock.part_end(0); g_clock.part_begin();
         save_model();
+        g_clock.part_end(1); g_clock.part_begin();
         compute_precision(false);
+        g_clock.part_end(2); g_clock.part_begin();
         if (env.hier || !env.bias) compute_itemrank(false);   // vb_bias() has no itemrank call
+        g_clock.part_end(3);
         if (env.logl) {                          // HGAPRec::logl, hgaprec.cc:2160-2255
           double v = 0.0;
           int rc2 = hpf_elbo(h, &v);
@@ -606,6 +649,7 @@ struct Driver {
         do_on_stop();
       }
       if (env.checkpoint_every && iter > 0 && iter % env.checkpoint_every == 0) write_checkpoint();
+      g_clock.acc_report += g_clock.lap();
       iter++;
     }
   }
@@ -711,6 +755,7 @@ int main(int argc, char **argv)
   } else env.prefix = env.make_prefix();
   if (comm.barrier()) return 1;
 
+  if (rank == 0) g_clock.mark("start-up (flags, output dir)");
   Ratings ratings;
   ratings.cap_n = env.n; ratings.cap_m = env.m;
   ratings.binary = env.binary_data; ratings.rating_threshold = env.rating_threshold;
@@ -771,8 +816,10 @@ int main(int argc, char **argv)
       }
     }
   }
+  g_clock.lap();
   if (!have_data) rc = ratings.read_train(env.datfname + "/train.tsv");
   if (rc) exit(-1);
+  if (rank == 0) g_clock.mark("train.tsv");
   if (rank == 0) {
     env.plog("training ratings", (uint32_t)ratings.nratings);
     uint32_t lu = 0, li = 0;
@@ -785,6 +832,7 @@ int main(int argc, char **argv)
     char st[1024];
     snprintf(st, sizeof st, "read %d users, %d movies, %d ratings", ratings.n, ratings.m, (uint32_t)ratings.nratings);
     env.plog("statistics", std::string(st));
+    g_clock.mark("byusers.tsv + byitems.tsv");
   }
   if (!env.batch) {
     if (rank == 0) { printf("Quitting. Online inference not implemented.\n"); fflush(stdout); }

@@ -106,7 +106,95 @@ def test_initial_state_matches_oracle(orc, hier, bias, seed):
             assert np.array_equal(got.reshape(want.shape), want), name   # same MT words, same IEEE ops
 
 
+def test_initial_state_on_many_threads_is_the_one_thread_state(orc, monkeypatch):
+    """above 2^16 elements the digamma / log half of a start state runs on the host's threads:
+    same bits as on one thread (HGAPREC_SAVE_THREADS=1), same values as the oracle"""
+    n, m, K = 1500, 700, 50                                  # theta 75 000, beta 35 000 elements
+    st = hostlib.initial_state(3, n, m, K, True, False)
+    monkeypatch.setenv("HGAPREC_SAVE_THREADS", "1")
+    one = hostlib.initial_state(3, n, m, K, True, False)
+    monkeypatch.delenv("HGAPREC_SAVE_THREADS")
+    monkeypatch.setenv("HGAPREC_SAVE_THREADS", "7")          # pieces that do not divide the count
+    odd = hostlib.initial_state(3, n, m, K, True, False)
+    for name in st:
+        assert np.array_equal(st[name], one[name]) and np.array_equal(st[name], odd[name]), name
+    M = orc.Model(n, m, K, True, False, False)
+    M.initialize(3)
+    for name in ("THETA_E", "BETA_E", "THETA_SHAPE", "BETA_RATE"):
+        assert np.array_equal(st[name].reshape(M.state(name).shape), M.state(name)), name
+    for name in ("THETA_ELOG", "BETA_ELOG"):
+        assert np.max(np.abs(st[name].reshape(M.state(name).shape) - M.state(name))) < 1e-14, name
+
+
 # -------------------------------------------------------------- reader -------
+@pytest.fixture(params=["token-by-token", "on-threads"], autouse=True)
+def reader_mode(request, monkeypatch):
+    """every test of this file runs with both readers: the token-by-token one (small files, its default)
+    and the one that parses a well-formed file in pieces on the host's threads, forced onto files of
+    any size with an odd number of threads (it must hand everything else back to the first)"""
+    if request.param == "on-threads":
+        monkeypatch.setenv("HGAPREC_READ_PARALLEL_MIN", "0")
+        monkeypatch.setenv("HGAPREC_READ_THREADS", "3")
+    else:
+        monkeypatch.setenv("HGAPREC_READ_THREADS", "1")
+    return request.param
+
+
+def test_reader_on_threads_equals_token_by_token_on_a_file_that_takes_the_fast_path(orc, tmp_path, monkeypatch, reader_mode):
+    """3e5 records, users grouped and not, ratings 0 mixed in, ids that first appear in a later piece;
+    2 .. 13 threads; capacities that bind (the fall-back inside the fast path) and that do not"""
+    if reader_mode != "on-threads":
+        pytest.skip("compares the two readers itself")
+    rng = np.random.default_rng(11)
+    R = 300_000
+    u = np.sort(rng.integers(5, 40_000, R)).astype(np.int64)
+    u[R // 2:] = rng.integers(5, 60_000, R - R // 2)          # second half: not grouped, new users late
+    it = (rng.zipf(1.3, R) % 9_000).astype(np.int64) + 1
+    y = rng.integers(0, 6, R).astype(np.int64)
+    rows = np.stack([u, it, y], 1)
+    np.savetxt(tmp_path / "train.tsv", rows, fmt="%d", delimiter="\t")
+    np.savetxt(tmp_path / "validation.tsv", rows[::7] + np.array([0, 0, 1]), fmt="%d", delimiter="\t")
+    np.savetxt(tmp_path / "test.tsv", rows[3::11][:, [0, 1, 2]] + np.array([1, 0, 0]), fmt="%d", delimiter=" ")
+    for cap_n, cap_m in ((100_000, 100_000), (30_000, 100_000), (100_000, 2_000)):
+        def read(threads):
+            monkeypatch.setenv("HGAPREC_READ_THREADS", str(threads))
+            H = hostlib.Ratings(cap_n, cap_m, False, 1)
+            assert H.read_train(tmp_path / "train.tsv") == 0
+            for w, name in ((0, "validation.tsv"), (1, "test.tsv")):
+                assert H.read_heldout(tmp_path / name, w) == 0
+            return H
+        ref = read(1)
+        assert ref.nnz > 0.7 * R or cap_n < 100_000 or cap_m < 100_000
+        for threads in (2, 5, 13):
+            _assert_same(read(threads), ref)
+    O = orc.Ratings(30_000, 100_000, False, 1)                  # and the oracle on the case with a binding capacity
+    assert O.read_train(tmp_path / "train.tsv") == 0
+    monkeypatch.setenv("HGAPREC_READ_THREADS", "5")
+    H = hostlib.Ratings(30_000, 100_000, False, 1)
+    assert H.read_train(tmp_path / "train.tsv") == 0
+    assert (H.n, H.m, H.nnz) == (O.n, O.m, O.nnz) and np.array_equal(H.seq2user(), O.seq2user())
+    for a, b in zip(H.csr(), O.csr()):
+        assert np.array_equal(a, b)
+
+
+def test_reader_hands_unusual_files_back(tmp_path, monkeypatch, reader_mode):
+    """a sign, a letter, a token count that is no multiple of three: the token-by-token reader's result"""
+    cases = {"sign": "1 2 3\n4 -5 1\n6 7 2\n", "short": "1 2 3\n4 5 1\n6 7\n", "letter": "1 2 3\n4 x 1\n", "plus": "+1 2 3\n4 5 +1\n"}
+    for name, text in cases.items():
+        (tmp_path / f"{name}.tsv").write_text(text)
+        H = hostlib.Ratings(10, 10)
+        rc = H.read_train(tmp_path / f"{name}.tsv")
+        monkeypatch.setenv("HGAPREC_READ_THREADS", "1")
+        S = hostlib.Ratings(10, 10)
+        assert S.read_train(tmp_path / f"{name}.tsv") == rc
+        monkeypatch.setenv("HGAPREC_READ_THREADS", "3")
+        assert (H.n, H.m, H.nnz) == (S.n, S.m, S.nnz)
+        if rc == 0:
+            for a, b in zip(H.csr(), S.csr()):
+                assert np.array_equal(a, b)
+    assert hostlib.Ratings(10, 10).read_train(tmp_path / "letter.tsv") == -2
+
+
 def _both_readers(orc, tmp_path, train, valid, test, cap_n, cap_m, binary=False, thr=1):
     write_tsv(tmp_path / "train.tsv", train)
     write_tsv(tmp_path / "validation.tsv", valid)
