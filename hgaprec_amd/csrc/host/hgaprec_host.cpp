@@ -718,25 +718,53 @@ void Mt19937::set(unsigned long s)
   mti = 624;
 }
 
-uint32_t Mt19937::next_u32()
+void Mt19937::refill()
 {
-  if (mti >= 624) {
-    auto twist = [](uint32_t u, uint32_t v) {
-      const uint32_t y = (u & 0x80000000U) | (v & 0x7fffffffU);
-      return (y >> 1) ^ ((v & 1U) ? 0x9908b0dfU : 0U);
-    };
-    int kk = 0;
-    for (; kk < 624 - 397; ++kk) mt[kk] = mt[kk + 397] ^ twist(mt[kk], mt[kk + 1]);
-    for (; kk < 623; ++kk) mt[kk] = mt[kk + (397 - 624)] ^ twist(mt[kk], mt[kk + 1]);
-    mt[623] = mt[396] ^ twist(mt[623], mt[0]);
-    mti = 0;
-  }
-  uint32_t k = mt[mti++];
+  auto twist = [](uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000U) | (v & 0x7fffffffU);
+    return (y >> 1) ^ ((v & 1U) ? 0x9908b0dfU : 0U);
+  };
+  int kk = 0;
+  for (; kk < 624 - 397; ++kk) mt[kk] = mt[kk + 397] ^ twist(mt[kk], mt[kk + 1]);
+  for (; kk < 623; ++kk) mt[kk] = mt[kk + (397 - 624)] ^ twist(mt[kk], mt[kk + 1]);
+  mt[623] = mt[396] ^ twist(mt[623], mt[0]);
+  mti = 0;
+}
+
+static inline uint32_t mt_temper(uint32_t k)
+{
   k ^= (k >> 11);
   k ^= (k << 7) & 0x9d2c5680U;
   k ^= (k << 15) & 0xefc60000U;
   k ^= (k >> 18);
   return k;
+}
+
+uint32_t Mt19937::next_u32()
+{
+  if (mti >= 624) refill();
+  return mt_temper(mt[mti++]);
+}
+
+// the next cnt values of uniform(), scaled: out[j] = base + scale * uniform().  The same words in the same
+// order as cnt calls of next_u32(); a block of the state is tempered in one branch-free loop.
+void Mt19937::fill_affine(double *out, size_t cnt, double base, double scale)
+{
+  while (cnt) {
+    if (mti >= 624) refill();
+    const size_t c = std::min<size_t>(cnt, (size_t)(624 - mti));
+    const uint32_t *w = mt + mti;
+    for (size_t j = 0; j < c; ++j) out[j] = base + scale * (mt_temper(w[j]) / 4294967296.0);
+    mti += (int)c; out += c; cnt -= c;
+  }
+}
+void Mt19937::skip(size_t cnt)
+{
+  while (cnt) {
+    if (mti >= 624) refill();
+    const size_t c = std::min<size_t>(cnt, (size_t)(624 - mti));
+    mti += (int)c; cnt -= c;
+  }
 }
 
 unsigned long Mt19937::uniform_int(unsigned long n)
@@ -778,24 +806,6 @@ const double SPRIOR = 0.3, RPRIOR = 0.3;       // hgaprec.cc:13-20
 // Each helper draws for ALL `rows` rows (the stream position is what the
 // reference's is) and stores only rows [lo, hi).
 
-// GPMatrix::initialize (gpbase.hh:292-308): rows*k shape draws, then k rate draws
-void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate, uint32_t lo, uint32_t hi,
-                   std::vector<double> &shape, std::vector<double> &rate)
-{
-  shape.resize((size_t)(hi - lo) * k);
-  for (uint32_t i = 0; i < rows; ++i)
-    for (uint32_t j = 0; j < k; ++j) {
-      const double v = SPRIOR + 0.01 * r.uniform();
-      if (i >= lo && i < hi) shape[(size_t)(i - lo) * k + j] = v;
-    }
-  std::vector<double> b0(k);
-  for (uint32_t j = 0; j < k; ++j) b0[j] = RPRIOR + 0.1 * r.uniform();
-  if (global_rate) rate = b0;                   // GPMatrixGR::initialize gpbase.hh:651-663
-  else {
-    rate.resize((size_t)(hi - lo) * k);
-    for (uint32_t i = 0; i < hi - lo; ++i) for (uint32_t j = 0; j < k; ++j) rate[(size_t)i * k + j] = b0[j];
-  }
-}
 // elements [0, cnt) in equal pieces on the host's threads (capped at 32; HGAPREC_SAVE_THREADS overrides); every
 // element is computed by the same scalar code whichever thread takes it, so the result does not depend on the count
 template <typename F>
@@ -814,18 +824,35 @@ void parallel_pieces(size_t cnt, F fn)
   }
   for (auto &x : th) x.join();
 }
+// GPMatrix::initialize (gpbase.hh:292-308): rows*k shape draws, then k rate draws
+void gp_initialize(Mt19937 &r, uint32_t rows, uint32_t k, bool global_rate, uint32_t lo, uint32_t hi,
+                   StateArray &shape, StateArray &rate)
+{
+  shape.resize((size_t)(hi - lo) * k);
+  r.skip((size_t)lo * k);                                     // rows of other ranks: drawn, not kept
+  r.fill_affine(shape.data(), shape.size(), SPRIOR, 0.01);    // SPRIOR + 0.01 * uniform(), row by row
+  r.skip((size_t)(rows - hi) * k);
+  std::vector<double> b0(k);
+  for (uint32_t j = 0; j < k; ++j) b0[j] = RPRIOR + 0.1 * r.uniform();
+  if (global_rate) rate.assign(b0.begin(), b0.end());                   // GPMatrixGR::initialize gpbase.hh:651-663
+  else {
+    rate.resize((size_t)(hi - lo) * k);
+    double *pr = rate.data(); const double *pb = b0.data();
+    parallel_pieces((size_t)(hi - lo), [pr, pb, k](size_t r0, size_t r1) {
+      for (size_t i = r0; i < r1; ++i) for (uint32_t j = 0; j < k; ++j) pr[i * k + j] = pb[j];
+    });
+  }
+}
 // initialize_exp (gpbase.hh:324-340 / 700-715): fresh rate draw per element.  The draws are taken in the
 // reference's order by one thread; digamma and log of the kept rows -- nine tenths of the time of a start
 // state (C2: 1.1e8 elements) -- go to the host's threads afterwards.
 void gp_initialize_exp(Mt19937 &r, uint32_t rows, uint32_t k, uint32_t lo, uint32_t hi,
-                       const std::vector<double> &shape, std::vector<double> &E, std::vector<double> &Elog)
+                       const StateArray &shape, StateArray &E, StateArray &Elog)
 {
   E.resize(shape.size()); Elog.resize(shape.size());
-  for (uint32_t i = 0; i < rows; ++i)
-    for (uint32_t j = 0; j < k; ++j) {
-      const double b = RPRIOR + 0.1 * r.uniform();
-      if (i >= lo && i < hi) E[(size_t)(i - lo) * k + j] = b;          // the rate for now
-    }
+  r.skip((size_t)lo * k);
+  r.fill_affine(E.data(), E.size(), RPRIOR, 0.1);             // RPRIOR + 0.1 * uniform(): the rate for now
+  r.skip((size_t)(rows - hi) * k);
   const double *sh = shape.data();
   double *pe = E.data(), *pl = Elog.data();
   parallel_pieces(shape.size(), [sh, pe, pl](size_t a, size_t b2) {
@@ -837,8 +864,8 @@ void gp_initialize_exp(Mt19937 &r, uint32_t rows, uint32_t k, uint32_t lo, uint3
   });
 }
 // initialize2(v) + compute_expectations (gpbase.hh:310-322,939-949; 248-262,912-925)
-void gp_initialize2(Mt19937 &r, uint32_t rows, double v, uint32_t lo, uint32_t hi, std::vector<double> &shape,
-                    std::vector<double> &rate, std::vector<double> &E, std::vector<double> &Elog)
+void gp_initialize2(Mt19937 &r, uint32_t rows, double v, uint32_t lo, uint32_t hi, StateArray &shape,
+                    StateArray &rate, StateArray &E, StateArray &Elog)
 {
   const uint32_t keep = hi - lo;
   shape.resize(keep); rate.resize(keep); E.resize(keep); Elog.resize(keep);
@@ -963,37 +990,46 @@ static void format_rows(const double *a, uint32_t r0, uint32_t r1, uint32_t cols
   *len = pos;
 }
 
-// Formatting is the cost of a save (330 M numbers at C2): above ~2 M numbers the
-// row blocks are formatted by all host threads, a wave of blocks at a time, and
-// written in order -- the bytes are those of the serial writer.
+// A save is 330 M numbers at C2, 3.3 GB of text per report step: above ~2 M numbers the row blocks are
+// formatted by the host's threads, a wave of blocks at a time, and written in order WHILE the next wave is
+// being formatted (two sets of buffers) -- the bytes are those of the serial writer.  `threads` = 0: all of
+// the host's (HGAPREC_SAVE_THREADS overrides; at most 64).
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
-                const uint32_t *seq2id, uint32_t nids, uint32_t row0)
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0, unsigned threads)
 {
   FILE *tf = fopen(path.c_str(), "w");
   if (!tf) return -1;
-  unsigned nt = std::thread::hardware_concurrency();
+  unsigned nt = threads ? threads : std::thread::hardware_concurrency();
   if (const char *e = getenv("HGAPREC_SAVE_THREADS")) nt = (unsigned)atoi(e);
   if (nt < 1) nt = 1;
   if (nt > 64) nt = 64;
   if ((uint64_t)rows * cols < (2u << 20)) nt = 1;
   const uint32_t blk = std::max<uint32_t>(1, (uint32_t)((1u << 18) / std::max<uint32_t>(cols, 1)));   // ~256 K numbers
-  std::vector<std::vector<char>> bufs(nt);
-  std::vector<size_t> lens(nt, 0);
+  std::vector<std::vector<char>> bufs[2] = {std::vector<std::vector<char>>(nt), std::vector<std::vector<char>>(nt)};
+  std::vector<size_t> lens[2] = {std::vector<size_t>(nt, 0), std::vector<size_t>(nt, 0)};
   bool ok = true;
-  for (uint32_t r = 0; r < rows && ok; r += blk * nt) {
+  std::thread writer;
+  int set = 0;
+  for (uint32_t r = 0; r < rows; r += blk * nt, set ^= 1) {
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t) {
       const uint32_t r0 = r + t * blk;
-      lens[t] = 0;
+      lens[set][t] = 0;
       if (r0 >= rows) continue;
       const uint32_t r1 = (uint32_t)std::min<uint64_t>(rows, (uint64_t)r0 + blk);
-      if (nt == 1) format_rows(a, r0, r1, cols, seq2id, nids, row0, bufs[t], &lens[t]);
-      else th.emplace_back(format_rows, a, r0, r1, cols, seq2id, nids, row0, std::ref(bufs[t]), &lens[t]);
+      if (nt == 1) format_rows(a, r0, r1, cols, seq2id, nids, row0, bufs[set][t], &lens[set][t]);
+      else th.emplace_back(format_rows, a, r0, r1, cols, seq2id, nids, row0, std::ref(bufs[set][t]), &lens[set][t]);
     }
     for (auto &x : th) x.join();
-    for (unsigned t = 0; t < nt && ok; ++t)
-      if (lens[t]) ok = fwrite(bufs[t].data(), 1, lens[t], tf) == lens[t];
+    if (writer.joinable()) writer.join();         // the previous wave is on its way before this one follows
+    if (!ok) break;
+    auto put = [&, set]() {
+      for (unsigned t = 0; t < nt && ok; ++t)
+        if (lens[set][t]) ok = fwrite(bufs[set][t].data(), 1, lens[set][t], tf) == lens[set][t];
+    };
+    if (nt == 1) put(); else writer = std::thread(put);
   }
+  if (writer.joinable()) writer.join();
   ok = (fclose(tf) == 0) && ok;
   return ok ? 0 : -1;
 }

@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace hgaprec {
@@ -135,6 +137,11 @@ struct Mt19937 {
   explicit Mt19937(unsigned long seed = 0) { set(seed); }
   void set(unsigned long seed);
   uint32_t next_u32();
+  void refill();
+  // out[j] = base + scale * uniform() for the next cnt draws / cnt draws taken and dropped: the stream
+  // position afterwards is that of cnt calls of next_u32()
+  void fill_affine(double *out, size_t cnt, double base, double scale);
+  void skip(size_t cnt);
   double uniform() { return next_u32() / 4294967296.0; }
   unsigned long uniform_int(unsigned long n);
 };
@@ -143,14 +150,22 @@ double digamma(double x);      // x > 0, |err| ~ 1e-15 (stands for gsl_sf_psi)
 
 // ---------------------------------------------------------- GammaInit -----
 // Host arrays of the start state, in the layout of hpf_set_state.
+// resize() of these arrays does not write zeros first: every element is assigned by initialize_state, and at
+// C2 the four user-side matrices are 3.5 GB that would otherwise be touched twice
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  template <typename U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <typename U, typename... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+using StateArray = std::vector<double, NoInitAlloc<double>>;
 struct GammaState {
   uint32_t n = 0, m = 0, k = 0; bool hier = false, bias = false;
-  std::vector<double> theta_shape, theta_rate, theta_E, theta_Elog;
-  std::vector<double> beta_shape, beta_rate, beta_E, beta_Elog;
-  std::vector<double> xi_shape, xi_rate, xi_E, xi_Elog;
-  std::vector<double> eta_shape, eta_rate, eta_E, eta_Elog;
-  std::vector<double> ubias_shape, ubias_rate, ubias_E, ubias_Elog;
-  std::vector<double> ibias_shape, ibias_rate, ibias_E, ibias_Elog;
+  StateArray theta_shape, theta_rate, theta_E, theta_Elog;
+  StateArray beta_shape, beta_rate, beta_E, beta_Elog;
+  StateArray xi_shape, xi_rate, xi_E, xi_Elog;
+  StateArray eta_shape, eta_rate, eta_E, eta_Elog;
+  StateArray ubias_shape, ubias_rate, ubias_E, ubias_Elog;
+  StateArray ibias_shape, ibias_rate, ibias_E, ibias_Elog;
 };
 // hgaprec.cc:153-204 with the RNG already seeded as hgaprec.cc:34-38.
 // [user_lo, user_hi): keep only that range of the user-side arrays (a rank's
@@ -169,8 +184,9 @@ Mt19937 make_rng(double env_seed);
 // "%.8f" exactly as printf rounds it, ~10x faster; returns the length (no NUL)
 size_t format_fixed8(double v, char *out);
 // row0: sequence number of the first row (a rank writing its shard of a matrix)
+// threads: how many host threads format the rows (0 = all of them)
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
-                const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0);
+                const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0, unsigned threads = 0);
 int save_vector(const std::string &path, const double *a, uint32_t rows,
                 const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0);
 

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <ctime>
 #include <sys/wait.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -41,6 +42,7 @@ namespace {
 struct PhaseClock {
   bool on = getenv("HPF_CLI_TIMING") != nullptr;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double acc_get = 0, acc_join = 0;     // inside save_model: hpf_get_state, waiting for the file writers after the last fetch
   double acc_iter = 0, acc_report = 0, acc_part[5] = {0, 0, 0, 0, 0};   // parts: likelihood, save_model, precision, itemrank, on stop
   std::chrono::steady_clock::time_point p0;
   void part_begin() { p0 = std::chrono::steady_clock::now(); }
@@ -51,6 +53,10 @@ struct PhaseClock {
     t0 = t1;
     return s;
   }
+  static double epoch() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+  void stamp(const char *what) { if (on) fprintf(stderr, "[timing-epoch] %s %.6f\n", what, epoch()); }   // for the caller's own clock (tools/cli_walltime.py)
+  double acc_other = 0;                 // time between the named phases (logging, small files, frees)
+  void other() { acc_other += lap(); }
   void mark(const char *what) { const double s = lap(); if (on) fprintf(stderr, "[timing] %-28s %9.3f s\n", what, s); }
   void totals(uint32_t iterations) {
     if (!on) return;
@@ -58,6 +64,8 @@ struct PhaseClock {
             "report steps + saves", acc_report, "iterations run", iterations);
     const char *nm[5] = {"  held-out likelihood", "  save_model", "  compute_precision", "  compute_itemrank", "  on stop (save + ranking)"};
     for (int j = 0; j < 5; ++j) fprintf(stderr, "[timing] %-28s %9.3f s\n", nm[j], acc_part[j]);
+    fprintf(stderr, "[timing] %-28s %9.3f s\n[timing] %-28s %9.3f s\n", "  saves: hpf_get_state", acc_get, "  saves: waiting for writers", acc_join);
+    fprintf(stderr, "[timing] %-28s %9.3f s\n", "between the phases", acc_other);
   }
 };
 PhaseClock g_clock;
@@ -76,6 +84,7 @@ struct Driver {
   std::vector<uint32_t> item_deg;      // _movies[m]->size()
   HeldOut lvalid, ltest;               // this rank's held-out pairs, LOCAL user indices
   std::vector<double> xbuf;            // host staging of the exchange buffer (-comm host)
+  std::vector<double> save_u[3], save_i[3];   // host copies of an object's shape / rate / expectation while they are written
 
   Driver(Env &e, Ratings &r, Comm &c) : env(e), rt(r), comm(c), n(r.n), m(r.m), k(e.k), start(time(0)) {}
 
@@ -127,7 +136,7 @@ struct Driver {
       }
     }
     // load_validation_and_test_sets (hgaprec.cc:110-151): both must open
-    g_clock.lap();
+    g_clock.other();
     if (!rt.heldout_loaded) {                     // else: came with the -cache image
       int rc = rt.read_heldout(env.datfname + "/validation.tsv", &rt.validation);
       assert(rc != -1);
@@ -203,10 +212,10 @@ struct Driver {
   void initialize() {
     rng = make_rng(env.seed);
     GammaState s;
-    g_clock.lap();
+    g_clock.other();
     initialize_state(rng, n, m, k, env.hier, env.bias, &s, lo, hi);
     g_clock.mark("start state (MT19937, host)");
-    auto put = [&](hpf_state w, const std::vector<double> &v) {
+    auto put = [&](hpf_state w, const StateArray &v) {
       int rc = hpf_set_state(h, w, v.data(), v.size());
       if (rc) die("hpf_set_state", rc);
     };
@@ -296,36 +305,53 @@ struct Driver {
   }
   std::string my_path(const std::string &path) const { return comm.world == 1 ? path : part_name(path, comm.rank); }
 
-  // GP*::save_state (gpbase.hh:389-398,743-752,971-980)
+  // GP*::save_state (gpbase.hh:389-398,743-752,971-980).  The three matrices of an object (shape, rate,
+  // expectation) are fetched one after the other and written SIDE BY SIDE, a thread per file: one file's
+  // buffered writes are serial in the kernel, three files' are not, and at C2 a save is 3.3 GB of text
+  // whose formatting already runs on all threads (hgaprec_host.cpp save_matrix).
   void save_object(const char *name, hpf_state shape, bool user_side, uint32_t cols, bool vec_rate) {
     const uint32_t rows = user_side ? hi - lo : m, row0 = user_side ? lo : 0;
     const std::vector<uint32_t> &ids = user_side ? rt.seq2user : rt.seq2item;
     const bool mine = user_side || root();       // item-side state is replicated: rank 0 writes it
     const std::string base = env.file_str(std::string("/") + name);
-    std::vector<double> buf;
-    auto get = [&](hpf_state w, size_t cnt) {
-      buf.resize(cnt);
-      int rc = hpf_get_state(h, w, buf.data(), cnt);
+    std::vector<double> *buf = user_side ? save_u : save_i;   // kept between saves: 2.9 GB of fresh pages per report otherwise
+    auto get = [&](std::vector<double> &b, hpf_state w, size_t cnt) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (b.size() < cnt) b.resize(cnt);
+      int rc = hpf_get_state(h, w, b.data(), cnt);
       if (rc) die("hpf_get_state", rc);
+      g_clock.acc_get += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
     const char *suf[3] = {"_shape.tsv", "_rate.tsv", ".tsv"};
+    std::string dst[3];
+    int failed[3] = {0, 0, 0};
+    std::vector<std::thread> writers;
+    const unsigned per_file = std::max(1u, std::thread::hardware_concurrency() / 3);
     for (int j = 0; j < 3; ++j) {
       const std::string path = base + suf[j];
       const bool vec = j == 1 && vec_rate;       // GPMatrixGR rate: K-vector, ids looked up by k
       if (vec) {
         if (root()) {
-          get((hpf_state)(shape + 1), cols);
-          if (save_vector(path, buf.data(), cols, ids.data(), (uint32_t)ids.size())) io_die("cannot write", path);
+          get(buf[j], (hpf_state)(shape + 1), cols);
+          if (save_vector(path, buf[j].data(), cols, ids.data(), (uint32_t)ids.size())) io_die("cannot write", path);
         }
         continue;
       }
-      if (mine) {
-        get((hpf_state)(shape + j), (size_t)rows * cols);
-        const std::string dst = user_side ? my_path(path) : path;
-        if (save_matrix(dst, buf.data(), rows, cols, ids.data(), (uint32_t)ids.size(), row0)) io_die("cannot write", dst);
-      }
-      if (user_side) finish_parts(path);
+      if (!mine) continue;
+      get(buf[j], (hpf_state)(shape + j), (size_t)rows * cols);
+      dst[j] = user_side ? my_path(path) : path;
+      const double *a = buf[j].data();
+      const std::string *d = &dst[j];
+      int *bad = &failed[j];
+      const std::vector<uint32_t> *idv = &ids;
+      writers.emplace_back([=]() { *bad = save_matrix(*d, a, rows, cols, idv->data(), (uint32_t)idv->size(), row0, per_file); });
     }
+    const auto tw = std::chrono::steady_clock::now();
+    for (auto &w : writers) w.join();
+    g_clock.acc_join += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    for (int j = 0; j < 3; ++j) if (failed[j]) io_die("cannot write", dst[j]);
+    if (user_side)
+      for (int j = 0; j < 3; ++j) if (!(j == 1 && vec_rate)) finish_parts(base + suf[j]);
   }
   void save_array(const char *name, hpf_state shape, bool user_side) {
     const uint32_t rows = user_side ? hi - lo : m, row0 = user_side ? lo : 0;
@@ -544,9 +570,9 @@ struct Driver {
   }
 
   void finish(int code) {
-    g_clock.lap();
+    g_clock.other();
     if (h) { hpf_synchronize(h); hpf_destroy(h); h = nullptr; }
-    if (root()) { g_clock.totals(iter); g_clock.mark("hpf_destroy"); }
+    if (root()) { g_clock.totals(iter); g_clock.mark("hpf_destroy"); g_clock.stamp("exit"); }
     comm.barrier();
     comm.close_all();
     exit(code);
@@ -617,7 +643,7 @@ struct Driver {
     start_sums();
     while (1) {
       if (env.hier && iter > env.max_iterations) finish(0);
-      g_clock.lap();
+      g_clock.other();
       iterate();
       if (g_clock.on) hpf_synchronize(h);
       g_clock.acc_iter += g_clock.lap();
@@ -706,6 +732,7 @@ int spawn_ranks(int ngpus, char **argv)
 int main(int argc, char **argv)
 {
   signal(SIGTERM, term_handler);
+  g_clock.stamp("main");
   if (argc <= 1) {
     printf("gaprec -dir <netflix-dataset-dir> -n <users>"
            "-m <movies> -k <dims> -label <out-dir-tag>\n");
@@ -816,7 +843,7 @@ int main(int argc, char **argv)
       }
     }
   }
-  g_clock.lap();
+  g_clock.other();
   if (!have_data) rc = ratings.read_train(env.datfname + "/train.tsv");
   if (rc) exit(-1);
   if (rank == 0) g_clock.mark("train.tsv");

@@ -82,11 +82,22 @@ GammaState *hg_state_new(double seed, uint32_t n, uint32_t m, uint32_t k, int hi
   initialize_state(r, n, m, k, hier != 0, bias != 0, s);
   return s;
 }
+// the rows [lo, hi) of the user-side arrays, as a rank of several keeps them; *words_after = the generator's
+// next word afterwards (every rank must leave the stream where a single process does)
+GammaState *hg_state_new_range(double seed, uint32_t n, uint32_t m, uint32_t k, int hier, int bias,
+                               uint32_t lo, uint32_t hi, uint32_t *word_after)
+{
+  GammaState *s = new GammaState();
+  Mt19937 r = make_rng(seed);
+  initialize_state(r, n, m, k, hier != 0, bias != 0, s, lo, hi);
+  if (word_after) *word_after = r.next_u32();
+  return s;
+}
 void hg_state_free(GammaState *s) { delete s; }
 // which: the hpf_state index of include/hpf.h
 size_t hg_state_get(const GammaState *s, int which, const double **p)
 {
-  const std::vector<double> *v[24] = {
+  const StateArray *v[24] = {
     &s->theta_shape, &s->theta_rate, &s->theta_E, &s->theta_Elog,
     &s->beta_shape, &s->beta_rate, &s->beta_E, &s->beta_Elog,
     &s->xi_shape, &s->xi_rate, &s->xi_E, &s->xi_Elog,

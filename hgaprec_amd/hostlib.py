@@ -52,6 +52,9 @@ def lib():
     L.hg_digamma.argtypes = [C.c_double]; L.hg_digamma.restype = C.c_double
     L.hg_state_new.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     L.hg_state_new.restype = vp
+    L.hg_state_new_range.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_uint32)]
+    L.hg_state_new_range.restype = vp
     L.hg_state_free.argtypes = [vp]
     L.hg_state_get.argtypes = [vp, C.c_int, C.POINTER(dp)]; L.hg_state_get.restype = C.c_size_t
     L.hg_save_matrix.argtypes = [C.c_char_p, dp, C.c_uint32, C.c_uint32, u32p, C.c_uint32]
@@ -161,12 +164,20 @@ def digamma(x):
     return np.array([L.hg_digamma(float(v)) for v in np.atleast_1d(x)])
 
 
-def initial_state(seed, n, m, k, hier, bias) -> dict:
-    """HGAPRec::initialize on the host -> {state name: array} (hpf_set_state layout)"""
+def initial_state(seed, n, m, k, hier, bias, rows=None) -> dict:
+    """HGAPRec::initialize on the host -> {state name: array} (hpf_set_state layout).
+    rows = (lo, hi): the user-side arrays of that range only, as one rank of several keeps them;
+    the dict then also holds "_word_after", the generator's next 32-bit word."""
     from .capi import STATE_NAMES
     L = lib()
-    s = C.c_void_p(L.hg_state_new(float(seed), n, m, k, int(hier), int(bias)))
     out = {}
+    if rows is None:
+        s = C.c_void_p(L.hg_state_new(float(seed), n, m, k, int(hier), int(bias)))
+    else:
+        w = C.c_uint32(0)
+        s = C.c_void_p(L.hg_state_new_range(float(seed), n, m, k, int(hier), int(bias), int(rows[0]), int(rows[1]), C.byref(w)))
+        out["_word_after"] = int(w.value)
+        n = int(rows[1]) - int(rows[0])
     try:
         for idx, name in enumerate(STATE_NAMES):
             p = C.POINTER(C.c_double)()

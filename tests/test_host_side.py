@@ -106,6 +106,27 @@ def test_initial_state_matches_oracle(orc, hier, bias, seed):
             assert np.array_equal(got.reshape(want.shape), want), name   # same MT words, same IEEE ops
 
 
+@pytest.mark.parametrize("hier,bias", [(True, False), (True, True), (False, True)])
+def test_a_ranks_slice_of_the_start_state_is_the_slice_of_the_whole(hier, bias):
+    """a rank of several draws the whole stream and keeps rows [lo, hi) of the user side (block-wise
+    draws, dropped draws for the rows of others): the slice of the one-process state, bit for bit, the
+    item side whole, and the generator left at the same word"""
+    n, m, K = 700, 300, 130                                   # rows straddle the 624-word blocks of the generator
+    whole = hostlib.initial_state(5, n, m, K, hier, bias, rows=(0, n))
+    plain = hostlib.initial_state(5, n, m, K, hier, bias)
+    for name, a in plain.items():
+        assert np.array_equal(a, whole[name]), name
+    user_side = {"THETA_SHAPE", "THETA_E", "THETA_ELOG", "XI_SHAPE", "XI_RATE", "XI_E", "XI_ELOG",
+                 "UBIAS_SHAPE", "UBIAS_RATE", "UBIAS_E", "UBIAS_ELOG"} | ({"THETA_RATE"} if hier else set())
+    for lo, hi in ((0, 1), (1, 699), (250, 251), (333, 700), (700, 700)):
+        part = hostlib.initial_state(5, n, m, K, hier, bias, rows=(lo, hi))
+        assert part["_word_after"] == whole["_word_after"]
+        for name, a in plain.items():
+            got = part.get(name, np.zeros(0))
+            want = a[lo:hi] if name in user_side else a
+            assert np.array_equal(np.asarray(got).reshape(np.asarray(want).shape), want), (name, lo, hi)
+
+
 def test_initial_state_on_many_threads_is_the_one_thread_state(orc, monkeypatch):
     """above 2^16 elements the digamma / log half of a start state runs on the host's threads:
     same bits as on one thread (HGAPREC_SAVE_THREADS=1), same values as the oracle"""

@@ -59,6 +59,10 @@ for label, extra in (("text", []), ("cache_write", ["-cache"]), ("cache_read", [
                         "-rfreq", str(a.rfreq), "-max-iterations", str(a.iters)] + extra, cwd=td, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     ph = {m_.group(1).strip(): float(m_.group(2)) for m_ in re.finditer(r"^\[timing\] (.+?)\s+([0-9.]+)(?: s)?$", r.stderr, re.M)}
+    ep = {m_.group(1): float(m_.group(2)) for m_ in re.finditer(r"^\[timing-epoch\] (\w+) ([0-9.]+)$", r.stderr, re.M)}
+    if "main" in ep and "exit" in ep:       # what the binary's own phases cannot see: loading it, and leaving it
+        ph["before main (exec, shared libraries)"] = round(ep["main"] - t0, 3)
+        ph["after exit() was called"] = round(t0 + wall - ep["exit"], 3)
     res["runs"][label] = {"wall_s": round(wall, 2), "rc": r.returncode, "phases_s": ph}
     print(f"{label}: {wall:.2f}s rc={r.returncode}", flush=True)
     for k, v in ph.items():
