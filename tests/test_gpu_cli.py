@@ -371,6 +371,19 @@ def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
             assert np.array_equal(ia, ib), nm + suf
             assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf
             assert np.max(np.abs(va - vb)) <= 2.1e-8 + 1e-9 * np.max(np.abs(vb)), nm + suf
+    # the host side of that run was threaded (an 11 MB train.tsv is parsed in pieces, the CSR built per user range,
+    # the start state's expectations and the factor files formatted on all threads): one thread gives the same files
+    solo = tmp_path / "solo"
+    solo.mkdir()
+    r = subprocess.run([str(EXE)] + args, cwd=solo, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HGAPREC_READ_THREADS="1", HGAPREC_SAVE_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    skip = {"infer.log", "validation.txt", "test.txt", "max.txt"}        # these carry wall-clock seconds
+    names = sorted(p.name for p in out.iterdir() if p.name not in skip)
+    assert names == sorted(p.name for p in (solo / out.name).iterdir() if p.name not in skip)
+    for nm in names:
+        assert (out / nm).read_bytes() == (solo / out.name / nm).read_bytes(), nm
+    assert [x[1] for x in series(out / "validation.txt")] == [x[1] for x in series(solo / out.name / "validation.txt")]
 
 
 def test_sigterm_saves_state_on_the_following_iterations(tmp_path):
