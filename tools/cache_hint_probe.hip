@@ -107,7 +107,23 @@ int main()
   run<100>("global plain", hot, hr, cold, cr, clk, sink, false, 0);
   run<102>("global nt", hot, hr, cold, cr, clk, sink, false, 0);
   run<100>("global plain", hot, hr, cold, cr, clk, sink, false, 2);
-  run<102>("global nt", hot, hr, cold, cr, clk, sink, true, 2);
+  run<102>("global nt", hot, hr, cold, cr, clk, sink, false, 2);
+  // round 4: the policy as a property of the ALLOCATION instead of the instruction -- the cold matrix in memory the
+  // L2 does not keep (hipDeviceMallocUncached), or fine-grained; plain loads.  A per-nonzero choice between a cached
+  // and an uncached copy of a row would be a choice of ADDRESS: no second load form, no divergence.
+  for (int kind = 0; kind < 2; ++kind) {
+    unsigned char *c2 = nullptr;
+    const unsigned flag = kind == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+    const char *nm = kind == 0 ? "plain, cold rows in UNCACHED memory" : "plain, cold rows in FINE-GRAINED memory";
+    if (hipExtMallocWithFlags((void **)&c2, (size_t)cr * 768, flag) != hipSuccess) { printf("  {\"cold_loads\": \"%s\", \"error\": \"allocation failed\"},\n", nm); (void)hipGetLastError(); continue; }
+    CHECK(hipMemset(c2, 2, (size_t)cr * 768));
+    run<0>(nm, hot, hr, c2, cr, clk, sink, false, 2);
+    run<0>(nm, hot, hr, c2, cr, clk, sink, false, 4);
+    run<0>(nm, hot, hr, c2, cr, clk, sink, false, 0);
+    run<100>(nm, hot, hr, c2, cr, clk, sink, false, 2);
+    CHECK(hipFree(c2));
+  }
+  run<0>("plain", hot, hr, cold, cr, clk, sink, true, 2);
   printf("]}\n");
   return 0;
 }
