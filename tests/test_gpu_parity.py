@@ -67,6 +67,66 @@ def test_iterations_match_oracle(orc, K, hier, bias, binary):
         assert abs(ed - eo) <= 1e-10 * abs(eo), (it, ed, eo)
 
 
+def _random_case(j):
+    """case j of a fixed pseudo-random series: shape, flags, row layout and work-list knobs drawn together"""
+    rng = np.random.default_rng(9000 + j)
+    K = int(rng.choice([1, 2, 3, 4, 6, 9, 16, 17, 31, 32, 33, 48, 51, 63, 64, 65, 99, 100, 101, 127, 129, 160, 199, 255, 257, 320]))
+    hier = bool(rng.integers(2))
+    bias = bool(rng.integers(2))
+    binary = bool(rng.integers(4) == 0)
+    n = int(rng.choice([1, 2, 17, 64, 65, 150, 333]))
+    m = int(rng.choice([1, 2, 19, 64, 129, 250]))
+    nnz = int(max(n, m) * rng.choice([1, 3, 12, 40]))
+    env = {}
+    knob = int(rng.integers(5))
+    if knob == 1:
+        env = dict(HPF_TILE="1", HPF_TILE_BYTES=str(int(rng.choice([2048, 8192, 30000]))))
+    elif knob == 2:
+        env = dict(HPF_TILE="2", HPF_TILE_BYTES="4096", HPF_TILE_RUN=str(int(rng.choice([1, 2, 5]))), HPF_TILE_SHARE="1")
+    elif knob == 3:
+        env = dict(HPF_SEG_MAX=str(int(rng.choice([16, 20, 64]))), HPF_HUGE_SLOTS=str(int(rng.choice([2, 4, 9]))))
+    elif knob == 4:
+        env = dict(HPF_GRAPH=str(int(rng.integers(2))), HPF_SWEEP_BLOCKS=str(int(rng.choice([1, 3, 64]))))
+    kw = dict(heavy_user=bool(rng.integers(2)), heavy_item=bool(rng.integers(2)), singles=bool(rng.integers(2)))
+    return dict(K=K, hier=hier, bias=bias, binary=binary, n=n, m=m, nnz=nnz, env=env, prob_kw=kw,
+                w_storage=int(rng.choice([0, 0, 3])), val_mode=str(rng.choice(["ratings", "ratings", "wrap0"])),
+                iters=int(rng.integers(1, 5)), chunk=int(rng.integers(1, 4)))
+
+
+@pytest.mark.parametrize("j", range(40))
+def test_random_configurations_match_the_oracle(orc, monkeypatch, j):
+    """a differential sweep over combinations the parametrized tests do not enumerate: 1 .. 320 factors with and
+    without bias / hier / binary data, one-row and one-column matrices, rows of one rating and rows that hold everything,
+    ratings wrapped to 0, packed and plain rows, tiled and row-major lists with tiny tiles, short segments with the
+    two-level combine, hipGraph replay, several iterations per call"""
+    c = _random_case(j)
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+    for k, v in c["env"].items():
+        monkeypatch.setenv(k, v)
+    n, m = c["n"], c["m"]
+    M, D = _run_pair(orc, n, m, c["K"], c["nnz"], c["hier"], c["bias"], c["binary"], c["iters"], seed=300 + j,
+                     prob_kw=c["prob_kw"], val_mode=c["val_mode"], w_storage=c["w_storage"])
+    done = 0
+    while done < c["iters"]:
+        step = min(c["chunk"], c["iters"] - done)
+        M.iterate(step)
+        D.iterate(step)
+        done += step
+        for w in compare_states(c["hier"], c["bias"]):
+            dv, rf = np.asarray(D.get_state(w), np.float64), np.asarray(M.state(w), np.float64)
+            # element-wise relative error, except Elog = psi(shape) - log(rate), which may pass arbitrarily close to
+            # zero (case 25: 1.9e-9 of an entry of 1e-3): held to 1e-9 of max(|Elog|, 1), the quantity exp() is taken of
+            e = float(np.max(np.abs(dv - rf) / np.maximum(np.abs(rf), 1.0))) if w.endswith("ELOG") else rel_err(dv, rf)
+            assert e < RTOL, f"case {j} {c}: after {done} iterations {w}: rel err {e:.3e}"
+    hu, hi, hy = heldout_pairs(n, m, min(200, n * m), seed=j)
+    so = M.heldout_sum(hu, hi, hy)
+    sd, cnt = D.heldout_ll(hu, hi, hy)
+    assert cnt == hu.size and abs(sd - so) <= 1e-9 * max(1, hu.size), (j, c, sd, so)
+    eo, ed = M.elbo(), D.elbo()
+    assert abs(ed - eo) <= 1e-10 * abs(eo), (j, c, ed, eo)
+    D.close()
+
+
 def test_vb_bias_novb_uses_the_previous_iterations_sums(orc):
     """-bias -novb without -hier: vb_bias()'s else-branch (hgaprec.cc:1276-1297).  Both rates
     come from the expectations of the previous iteration -- the item rate takes
