@@ -369,6 +369,20 @@ def test_writers_match_reference_format(tmp_path):
         assert (tmp_path / "v.tsv").read_text() == c["vector_tsv"]
 
 
+def test_a_save_over_a_longer_file_leaves_no_tail(tmp_path):
+    """model files are rewritten in place (no truncation up front, the length set at the end): a shorter matrix or
+    vector over a longer file must leave exactly the new text"""
+    rng = np.random.default_rng(2)
+    big, small = rng.gamma(0.3, 1.0, size=(400, 7)), rng.gamma(0.3, 1.0, size=(13, 7))
+    for a in (big, small, big[:50]):
+        assert hostlib.save_matrix(tmp_path / "m.tsv", a, None) == 0
+        assert hostlib.save_matrix(tmp_path / "fresh.tsv", a, None) == 0
+        assert (tmp_path / "m.tsv").read_bytes() == (tmp_path / "fresh.tsv").read_bytes()
+        (tmp_path / "fresh.tsv").unlink()
+        assert hostlib.save_vector(tmp_path / "v.tsv", a[:, 0].copy(), None) == 0
+        assert len((tmp_path / "v.tsv").read_text().splitlines()) == a.shape[0]
+
+
 # ----------------------------------------------------------- stop rule -------
 def test_parallel_matrix_writer_is_byte_identical(tmp_path, monkeypatch):
     # large matrices are formatted by several threads, a wave of row blocks at a
