@@ -983,8 +983,11 @@ static FILE *open_rewrite(const std::string &path)
 static bool close_rewrite(FILE *f)
 {
   bool ok = fflush(f) == 0;
-  const off_t end = ftello(f);
-  ok = ok && end >= 0 && ftruncate(fileno(f), end) == 0;
+  struct stat st;
+  if (ok && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode)) {      // (a pipe or /dev/null has no length to set)
+    const off_t end = ftello(f);
+    ok = end >= 0 && ftruncate(fileno(f), end) == 0;
+  }
   return (fclose(f) == 0) && ok;
 }
 

@@ -21,7 +21,6 @@ ap.add_argument("--config", default="mid")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--rfreq", type=int, default=10)
 ap.add_argument("--out", default=None)
-ap.add_argument("--threads", default=None, help="HPF_HOST_THREADS for the binary")
 a = ap.parse_args()
 
 if a.config == "mid":
@@ -51,8 +50,6 @@ res = {"config": a.config, "n": n, "m": m, "nnz": int(u.size), "K": K, "iters": 
 print(f"wrote TSVs ({res['train_tsv_MB']:.0f} MB train) in {time.time() - t0:.1f}s", flush=True)
 exe = Path(__file__).resolve().parent.parent / "hgaprec_amd" / "hgaprec"
 env = dict(os.environ, HPF_CLI_TIMING="1")
-if a.threads:
-    env["HPF_HOST_THREADS"] = a.threads
 for label, extra in (("text", []), ("cache_write", ["-cache"]), ("cache_read", ["-cache"])):
     t0 = time.time()
     r = subprocess.run([str(exe), "-dir", str(td), "-n", str(n), "-m", str(m), "-k", str(K), "-hier",
