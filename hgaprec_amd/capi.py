@@ -39,9 +39,35 @@ EXPORTS = [
     "hpf_algorithmic_bytes",
     "hpf_snapshot_size", "hpf_snapshot_save", "hpf_snapshot_load",
     "hpf_get_work_info", "hpf_upload_csr_device", "hpf_get_csc", "hpf_set_state_device", "hpf_get_state_device",
-    "hpf_iteration_times", "hpf_debug_poke_index", "hpf_start_sums",
+    "hpf_iteration_times", "hpf_debug_poke_index", "hpf_start_sums", "hpf_host_alloc", "hpf_host_free",
 ]
 
+
+
+class _PinnedBlock:
+    """owner of one hpf_host_alloc block (freed with the last array that views it)"""
+    def __init__(self, lib, nbytes):
+        self.lib, self.ptr = lib, C.c_void_p()
+        rc = lib.hpf_host_alloc(C.byref(self.ptr), nbytes)
+        if rc != 0:
+            raise HpfError(f"hpf_host_alloc({nbytes}): {lib.hpf_strerror(rc).decode()}")
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and self.ptr.value:
+            self.lib.hpf_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """an uninitialised numpy array in page-locked host memory (include/hpf.h, hpf_host_alloc): hpf_get_state /
+    hpf_set_state to and from it move at the rate of the DMA, with no staging copy"""
+    lib = load_library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    blk = _PinnedBlock(lib, max(1, n * dt.itemsize))
+    buf = (C.c_char * max(1, n * dt.itemsize)).from_address(blk.ptr.value)
+    buf._hpf_block = blk                    # the ctypes buffer is the array's base: keeps the block alive
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
 class HpfConfig(C.Structure):
     _fields_ = [
@@ -150,6 +176,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_exchange_read.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_exchange_write.argtypes = [vp, dp, C.c_size_t]
     lib.hpf_synchronize.argtypes = [vp]
+    lib.hpf_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hpf_host_free.argtypes = [C.c_void_p]
     lib.hpf_gather_only.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.hpf_last_timing.argtypes = [vp, C.POINTER(HpfTiming)]
     lib.hpf_mean_timing.argtypes = [vp, C.c_uint32, C.POINTER(HpfTiming)]
@@ -314,8 +342,13 @@ class Hpf:
             raise ValueError(f"{which}: expected shape {self.state_shape(which)}, got {a.shape}")
         self._check(self.lib.hpf_set_state(self._h, STATE[which], _ptr(a, C.c_double), a.size))
 
-    def get_state(self, which: str) -> np.ndarray:
-        out = np.empty(self.state_shape(which), dtype=np.float64)
+    def get_state(self, which: str, out: np.ndarray | None = None) -> np.ndarray:
+        """out: a C-contiguous float64 array of the state's shape to fill (e.g. from pinned_empty: the DMA then writes
+        it directly) instead of a fresh one"""
+        if out is None:
+            out = np.empty(self.state_shape(which), dtype=np.float64)
+        elif out.dtype != np.float64 or not out.flags.c_contiguous or out.shape != self.state_shape(which):
+            raise ValueError(f"{which}: out must be a C-contiguous float64 array of shape {self.state_shape(which)}")
         self._check(self.lib.hpf_get_state(self._h, STATE[which], _ptr(out, C.c_double), out.size))
         return out
 

@@ -70,6 +70,30 @@ struct PhaseClock {
 };
 PhaseClock g_clock;
 
+// A host buffer that is used again and again as the target of hpf_get_state: page-locked when the library can give
+// that (the DMA then writes it directly, hpf.h hpf_host_alloc), ordinary memory otherwise.  Never shrinks.
+struct SaveBuf {
+  double *p = nullptr; size_t cap = 0; bool pinned = false;
+  double *data() const { return p; }
+  void reserve(size_t cnt) {
+    if (cnt <= cap) return;
+    release();
+    void *q = nullptr;
+    if (hpf_host_alloc(&q, cnt * sizeof(double)) == HPF_OK) { p = (double *)q; pinned = true; }
+    else { p = (double *)malloc(cnt * sizeof(double)); pinned = false; }
+    if (!p) { fprintf(stderr, "error: out of host memory (%zu doubles)\n", cnt); exit(1); }
+    cap = cnt;
+  }
+  void release() {
+    if (p) { if (pinned) hpf_host_free(p); else free(p); }
+    p = nullptr; cap = 0;
+  }
+  ~SaveBuf() { release(); }
+  SaveBuf() = default;
+  SaveBuf(const SaveBuf &) = delete;
+  SaveBuf &operator=(const SaveBuf &) = delete;
+};
+
 struct Driver {
   Env &env; Ratings &rt; Comm &comm; hpf_handle *h = nullptr;
   uint32_t n, m, k, iter = 0;          // n: ALL users; lo..hi: this rank's range
@@ -84,7 +108,8 @@ struct Driver {
   std::vector<uint32_t> item_deg;      // _movies[m]->size()
   HeldOut lvalid, ltest;               // this rank's held-out pairs, LOCAL user indices
   std::vector<double> xbuf;            // host staging of the exchange buffer (-comm host)
-  std::vector<double> save_u[3], save_i[3];   // host copies of an object's shape / rate / expectation while they are written
+  SaveBuf save_u[3], save_i[3];        // host copies of an object's shape / rate / expectation while they are written
+  std::thread save_prealloc;           // page-locking them (0.2 s per GB) runs beside the start state, not inside the first save
 
   Driver(Env &e, Ratings &r, Comm &c) : env(e), rt(r), comm(c), n(r.n), m(r.m), k(e.k), start(time(0)) {}
 
@@ -199,6 +224,12 @@ struct Driver {
                  wi.tiles_user ? "tiled" : "row-major", wi.tiles_user, wi.tiles_item ? "tiled" : "row-major", wi.tiles_item);
     }
 
+    save_prealloc = std::thread([this]() {
+      for (int j = 0; j < 3; ++j) {
+        save_u[j].reserve((size_t)(hi - lo) * k);
+        if (root()) save_i[j].reserve((size_t)m * k);
+      }
+    });
     if (comm.world > 1 && use_rccl) {                      // bootstrap the RCCL communicator
       char id[HPF_COMM_ID_BYTES]; memset(id, 0, sizeof id);
       if (root() && (rc = hpf_comm_unique_id(id))) die("hpf_comm_unique_id (librccl.so missing?)", rc);
@@ -314,10 +345,11 @@ struct Driver {
     const std::vector<uint32_t> &ids = user_side ? rt.seq2user : rt.seq2item;
     const bool mine = user_side || root();       // item-side state is replicated: rank 0 writes it
     const std::string base = env.file_str(std::string("/") + name);
-    std::vector<double> *buf = user_side ? save_u : save_i;   // kept between saves: 2.9 GB of fresh pages per report otherwise
-    auto get = [&](std::vector<double> &b, hpf_state w, size_t cnt) {
+    if (save_prealloc.joinable()) save_prealloc.join();
+    SaveBuf *buf = user_side ? save_u : save_i;   // kept between saves: 2.9 GB of fresh pages per report otherwise
+    auto get = [&](SaveBuf &b, hpf_state w, size_t cnt) {
       const auto t0 = std::chrono::steady_clock::now();
-      if (b.size() < cnt) b.resize(cnt);
+      b.reserve(cnt);
       int rc = hpf_get_state(h, w, b.data(), cnt);
       if (rc) die("hpf_get_state", rc);
       g_clock.acc_get += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -571,6 +603,8 @@ struct Driver {
 
   void finish(int code) {
     g_clock.other();
+    if (save_prealloc.joinable()) save_prealloc.join();
+    for (int j = 0; j < 3; ++j) { save_u[j].release(); save_i[j].release(); }
     if (h) { hpf_synchronize(h); hpf_destroy(h); h = nullptr; }
     if (root()) { g_clock.totals(iter); g_clock.mark("hpf_destroy"); g_clock.stamp("exit"); }
     comm.barrier();

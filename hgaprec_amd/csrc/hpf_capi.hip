@@ -515,10 +515,24 @@ void par_memcpy(void *dst, const void *src, size_t bytes, unsigned T)
   for (auto &x : th) x.join();
 }
 
+// is this host pointer page-locked memory HIP knows (hpf_host_alloc, hipHostMalloc, hipHostRegister)?  Then it is the
+// DMA's own source / target: no staging, no host copy
+bool host_is_pinned(const void *p)
+{
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
 // contiguous host -> device; returns after the bytes have left `src`
 int h2d(hpf_handle *h, void *dst, const void *src, size_t bytes)
 {
   if (!bytes) return HPF_OK;
+  if (bytes >= (1u << 20) && host_is_pinned(src) && host_is_pinned((const char *)src + bytes - 1)) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
   if (h->xfer_mode == 2 && bytes >= (1u << 20)) {
     if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
       hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
@@ -554,6 +568,11 @@ int h2d(hpf_handle *h, void *dst, const void *src, size_t bytes)
 int d2h(hpf_handle *h, void *dst, const void *src, size_t bytes)
 {
   if (!bytes) return HPF_OK;
+  if (bytes >= (1u << 20) && host_is_pinned(dst) && host_is_pinned((char *)dst + bytes - 1)) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HPF_OK;
+  }
   if (h->xfer_mode == 2 && bytes >= (1u << 20)) {
     if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) {
       hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream);
@@ -2676,6 +2695,23 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if (!ok) { h->err = "no gather-only kernel for this shape"; return HPF_ERR_UNSUPPORTED; }
   if (e != hipSuccess) { h->err = std::string("gather-only probe: ") + hipGetErrorString(e); return HPF_ERR_HIP; }
   return check_launch(h, "gather-only probe");
+}
+
+int hpf_host_alloc(void **ptr, size_t bytes)
+{
+  if (!ptr) return HPF_ERR_INVALID;
+  *ptr = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); return HPF_ERR_NO_DEVICE; }
+  if (hipHostMalloc(ptr, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *ptr = nullptr; return HPF_ERR_OOM; }
+  return HPF_OK;
+}
+
+int hpf_host_free(void *ptr)
+{
+  if (!ptr) return HPF_OK;
+  if (hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return HPF_ERR_INVALID; }
+  return HPF_OK;
 }
 
 int hpf_synchronize(hpf_handle *h)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 5
+#define HPF_ABI_VERSION 6
 
 typedef struct hpf_handle hpf_handle;
 
@@ -357,6 +357,17 @@ int  hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out);
  * pass.  Never called by the product path. */
 int  hpf_debug_poke_index(hpf_handle *h, int side, uint64_t pos, uint32_t value,
                           uint32_t *old_value, uint32_t *owner_row);
+
+/* Page-locked host memory (ABI v6).  hpf_get_state / hpf_set_state / hpf_upload_csr / the snapshot calls
+ * accept any host pointer; ordinary (pageable) memory goes through the library's two pinned staging
+ * buffers and a host copy -- ~20 GB/s out of the device, ~45 GB/s into it on the MI355X boxes measured --
+ * while a buffer from hpf_host_alloc is the target of the DMA itself (57 GB/s either way,
+ * tools/d2h_probe.hip).  Worth it for buffers that are used again and again: the CLI's copies of the
+ * factor matrices, fetched at every report step (hgaprec.cc:1422 save_model).  No handle is needed;
+ * HPF_ERR_OOM when the memory cannot be had (the caller falls back to malloc), HPF_ERR_NO_DEVICE
+ * without a HIP device. */
+int  hpf_host_alloc(void **ptr, size_t bytes);
+int  hpf_host_free(void *ptr);
 
 int  hpf_synchronize(hpf_handle *h);
 int  hpf_last_timing(hpf_handle *h, hpf_timing *out);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_functions():
         assert getattr(lib, name) is not None
     hdr = (Path(capi.__file__).resolve().parent.parent / "include" / "hpf.h").read_text()
-    assert lib.hpf_abi_version() == int(re.search(r"#define HPF_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert lib.hpf_abi_version() == int(re.search(r"#define HPF_ABI_VERSION (\d+)", hdr).group(1)) == 6
     assert lib.hpf_strerror(0) == b"ok"
     assert b"device" in lib.hpf_strerror(-2)
 

@@ -186,3 +186,33 @@ def test_stray_tuning_variables_are_ignored(monkeypatch):
     w = info()
     assert w["user_segments"] > base["user_segments"] and w["ld"] == 32 and w["graph_replay"] == 0
     assert w["tiles_user"] > 1 and w["tiles_item"] > 1
+
+
+def test_page_locked_host_buffers_take_the_direct_route():
+    """hpf_host_alloc (ABI v6): a buffer from it is the DMA's own target / source -- same values as through
+    the staged route, and the block outlives nothing it should not (arrays keep it alive)"""
+    from hgaprec_amd import capi
+    from hgaprec_amd.capi import Hpf, pinned_empty
+    n, m, K = 30_000, 9_000, 100                       # THETA_*: 24 MB, above the 1 MB bar of the direct route
+    rng = np.random.default_rng(4)
+    D = Hpf(n, m, K, hier=True)
+    for name, rows in (("THETA", n), ("BETA", m)):
+        sh = 0.3 + rng.random((rows, K))
+        rt = 0.3 + rng.random((rows, K))
+        pin = pinned_empty((rows, K))
+        pin[...] = sh
+        D.set_state(f"{name}_SHAPE", pin)              # host -> device from pinned memory
+        D.set_state(f"{name}_RATE", rt)                # ... and from ordinary memory
+        got_pin = D.get_state(f"{name}_SHAPE", out=pinned_empty((rows, K)))
+        got = D.get_state(f"{name}_SHAPE")
+        assert np.array_equal(got_pin, sh) and np.array_equal(got, sh)
+        assert np.array_equal(D.get_state(f"{name}_RATE", out=pinned_empty((rows, K))), rt)
+    small = pinned_empty(7)                             # below the bar: the ordinary route, same result
+    x = pinned_empty((n,))
+    D.set_state("XI_SHAPE", np.full(n, 1.25))
+    assert np.array_equal(D.get_state("XI_SHAPE", out=x), np.full(n, 1.25))
+    del small
+    with pytest.raises(ValueError):
+        D.get_state("THETA_SHAPE", out=np.empty((n, K), np.float32))
+    D.close()
+    assert got_pin[0, 0] == sh[0, 0]                    # the pinned block is still there after the handle is gone
