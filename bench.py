@@ -647,6 +647,17 @@ def main():
         t0 = time.perf_counter()
         D2.get_state("THETA_E")
         handover["get_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        # the same into / out of page-locked memory (hpf_host_alloc, C-ABI v6): the DMA's own target, no staging copy
+        from hgaprec_amd.capi import pinned_empty
+        pin = pinned_empty((n_loc, K))
+        pin[...] = a
+        t0 = time.perf_counter()
+        D2.set_state("THETA_E", pin)
+        handover["set_state_pinned_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        t0 = time.perf_counter()
+        D2.get_state("THETA_E", out=pin)
+        handover["get_state_pinned_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        del pin
         D2.close()
         del rp_h, col_h, val_h, a
 
