@@ -445,7 +445,7 @@ int Ratings::read_generic_parallel(FILE *f, HeldOut *out)
   // held-out file: a record counts when both ids are registered and its rating class is not 0
   for (int pass = 0; pass < 2; ++pass) {
     on_threads(nt, [&](unsigned t) {
-      uint64_t o = kept[t], cnt = 0; uint32_t us = 0, ms = 0;
+      uint64_t o = pass ? kept[t] : 0, cnt = 0; uint32_t us = 0, ms = 0;       // (pass 0: kept[t] is being written by thread t - 1)
       for (uint64_t r = rec0(t), e = rec0(t + 1); r < e; ++r) {
         const uint32_t y = tok[3 * r + 2];
         if (!user2seq.find(tok[3 * r], &us) || !item2seq.find(tok[3 * r + 1], &ms) || input_rating_class(y) == 0) continue;

@@ -294,6 +294,67 @@ static void test_env()
   (void)e3.parse(2, (char **)argv3, false, &bad);
 }
 
+// ---- the threaded host paths (round 4): a ratings file parsed in pieces, the CSR built per user range, the start
+// state's expectations and the matrix writer on several threads -- the results of the one-thread paths, and (under
+// -fsanitize=thread, `make tsan`) no data race on the way
+static void test_threads()
+{
+  std::mt19937 g(5);
+  std::string text;
+  const int R = 60000;
+  for (int j = 0; j < R; ++j) {
+    const unsigned u = j < R / 2 ? 100u + (unsigned)(j / 9) : 100u + g() % 9000u;       // grouped, then scattered users
+    const unsigned i = 1u + (g() % 97u) * (g() % 41u);
+    text += std::to_string(u) + "\t" + std::to_string(i) + "\t" + std::to_string(g() % 6u) + "\n";
+  }
+  write_text(path("big.tsv"), text);
+  write_text(path("bigv.tsv"), text.substr(0, text.size() / 3 * 2));                       // may end inside a record: token-by-token then
+  auto read = [&](const char *threads, uint32_t cap_n, Ratings *r) {
+    setenv("HGAPREC_READ_THREADS", threads, 1);
+    setenv("HGAPREC_READ_PARALLEL_MIN", "0", 1);
+    r->cap_n = cap_n; r->cap_m = 100000;
+    CHECK(r->read_train(path("big.tsv")) == 0);
+    CHECK(r->read_heldout(path("bigv.tsv"), &r->validation) == 0);
+  };
+  for (uint32_t cap_n : {100000u, 3000u}) {                 // 3000: the capacity binds, the fast path hands its records back
+    Ratings one, many;
+    read("1", cap_n, &one);
+    read("5", cap_n, &many);
+    CHECK(one.n == many.n && one.m == many.m && one.nratings == many.nratings);
+    CHECK(one.rowptr == many.rowptr && one.col == many.col && one.val == many.val);
+    CHECK(one.seq2user == many.seq2user && one.seq2item == many.seq2item);
+    CHECK(one.validation.u == many.validation.u && one.validation.i == many.validation.i && one.validation.y == many.validation.y);
+    CHECK(cap_n < 100000u ? one.n == cap_n : one.n > 3000u);
+  }
+  unsetenv("HGAPREC_READ_THREADS"); unsetenv("HGAPREC_READ_PARALLEL_MIN");
+  // start state: 70 000 elements per matrix, above the bar of the threaded half
+  GammaState a, b;
+  setenv("HGAPREC_SAVE_THREADS", "1", 1);
+  { Mt19937 r = make_rng(3.0); initialize_state(r, 700, 300, 100, true, true, &a); }
+  setenv("HGAPREC_SAVE_THREADS", "6", 1);
+  { Mt19937 r = make_rng(3.0); initialize_state(r, 700, 300, 100, true, true, &b); }
+  CHECK(a.theta_Elog.size() == 70000 && std::equal(a.theta_Elog.begin(), a.theta_Elog.end(), b.theta_Elog.begin()));
+  CHECK(std::equal(a.theta_E.begin(), a.theta_E.end(), b.theta_E.begin()) && std::equal(a.theta_rate.begin(), a.theta_rate.end(), b.theta_rate.begin()));
+  CHECK(std::equal(a.beta_Elog.begin(), a.beta_Elog.end(), b.beta_Elog.begin()));
+  // three matrices side by side, each formatted on several threads while its previous wave is written
+  const uint32_t rows = 30000, cols = 80;                   // 2.4 M numbers: above the bar of the threaded writer
+  std::vector<double> mtx((size_t)rows * cols);
+  for (auto &v : mtx) v = (double)(g() % 100000u) / 977.0;
+  setenv("HGAPREC_SAVE_THREADS", "1", 1);
+  CHECK(save_matrix(path("solo.tsv"), mtx.data(), rows, cols, nullptr, 0) == 0);
+  setenv("HGAPREC_SAVE_THREADS", "4", 1);
+  {
+    std::vector<std::thread> th;
+    int bad[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j)
+      th.emplace_back([&, j]() { bad[j] = save_matrix(path(("side" + std::to_string(j) + ".tsv").c_str()), mtx.data(), rows, cols, nullptr, 0, 0, 4); });
+    for (auto &t : th) t.join();
+    const std::string want = read_text(path("solo.tsv"));
+    for (int j = 0; j < 3; ++j) CHECK(bad[j] == 0 && read_text(path(("side" + std::to_string(j) + ".tsv").c_str())) == want);
+  }
+  unsetenv("HGAPREC_SAVE_THREADS");
+}
+
 int main(int argc, char **argv)
 {
   char tmpl[] = "/tmp/hgaprec_selftest_XXXXXX";
@@ -306,6 +367,7 @@ int main(int argc, char **argv)
   test_cache();
   test_writers();
   test_state();
+  test_threads();
   test_comm();
   if (g_fail) { fprintf(stderr, "host_selftest: %d check(s) failed\n", g_fail); return 1; }
   printf("host_selftest ok\n");
