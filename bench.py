@@ -646,7 +646,10 @@ def main():
         handover["set_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
         t0 = time.perf_counter()
         D2.get_state("THETA_E")
-        handover["get_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)
+        handover["get_state_host_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)     # into a fresh array: first touch of its pages included
+        t0 = time.perf_counter()
+        D2.get_state("THETA_E", out=a)
+        handover["get_state_host_touched_GBps"] = round(a.nbytes / (time.perf_counter() - t0) / 1e9, 2)   # into memory that has been written before
         # the same into / out of page-locked memory (hpf_host_alloc, C-ABI v6): the DMA's own target, no staging copy
         from hgaprec_amd.capi import pinned_empty
         pin = pinned_empty((n_loc, K))

@@ -360,12 +360,14 @@ int  hpf_debug_poke_index(hpf_handle *h, int side, uint64_t pos, uint32_t value,
 
 /* Page-locked host memory (ABI v6).  hpf_get_state / hpf_set_state / hpf_upload_csr / the snapshot calls
  * accept any host pointer; ordinary (pageable) memory goes through the library's two pinned staging
- * buffers and a host copy -- ~20 GB/s out of the device, ~45 GB/s into it on the MI355X boxes measured --
- * while a buffer from hpf_host_alloc is the target of the DMA itself (57 GB/s either way,
- * tools/d2h_probe.hip).  Worth it for buffers that are used again and again: the CLI's copies of the
- * factor matrices, fetched at every report step (hgaprec.cc:1422 save_model).  No handle is needed;
- * HPF_ERR_OOM when the memory cannot be had (the caller falls back to malloc), HPF_ERR_NO_DEVICE
- * without a HIP device. */
+ * buffers and a threaded host copy -- on the MI355X boxes measured 44 GB/s out of the device into memory
+ * that has been written before, 11-14 GB/s into freshly allocated pages (their first touch is most of
+ * the time), 30-44 GB/s into the device -- while a buffer from hpf_host_alloc is the target of the DMA
+ * itself (54 GB/s either way; tools/d2h_probe.hip, bench.py --host-handover).  Worth it for buffers that
+ * are used again and again (page-locking costs ~0.15 s per GB, and as much again to undo): the CLI's
+ * copies of the factor matrices, fetched at every report step (hgaprec.cc:1422 save_model).  No handle
+ * is needed; HPF_ERR_OOM when the memory cannot be had (the caller falls back to malloc),
+ * HPF_ERR_NO_DEVICE without a HIP device. */
 int  hpf_host_alloc(void **ptr, size_t bytes);
 int  hpf_host_free(void *ptr);
 
