@@ -797,6 +797,44 @@ __device__ __forceinline__ PsiParts psi_parts(double x)
   return r;
 }
 
+// psi_parts for the row sweep, which also needs 1 / rate of the same element: the three reciprocals -- 1/P(x),
+// 1/(x + 10), 1/rate -- are ONE v_rcp_f64 (+ two Newton steps) of their product and six multiplies instead of three
+// reciprocals of five instructions each (C2 user sweep 0.445 -> 0.425 ms, profiles/r04/experiments.md 8).  P(x) <= 19^10,
+// the shifted x <= 20 and any rate a model can take keep the product far inside the range; where x >= 10 (no shift) P is
+// replaced by 1, so that an overflowed product never enters.  ri = 1 / rt to ~2 ulp (the exported E is an IEEE
+// division, materialize_es_kernel; this one feeds the column sums and W); corr as in psi_parts to a few 1e-16.
+struct PsiRate { double xs, corr, ri; };
+
+__device__ __forceinline__ PsiRate psi_parts_rate(double x, double rt)
+{
+  const bool small = x < 10.0;
+  const double t = x * (x + 9.0);
+  double p = t, dp = 1.0;
+  const double cj[4] = {8.0, 14.0, 18.0, 20.0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const double f = t + cj[j]; dp = fma(dp, f, p); p *= f; }
+  dp *= fma(2.0, x, 9.0);
+  const double pp = small ? p : 1.0;
+  const double xs = small ? x + 10.0 : x;
+  const double pq = pp * xs;
+  const double r = fast_rcp(pq * rt);
+  PsiRate o;
+  o.ri = r * pq;
+  const double ipq = r * rt;                    // 1 / (pp * xs)
+  const double xi = ipq * pp, x2 = xi * xi;
+  const double shift = small ? dp * (ipq * xs) : 0.0;
+  double sr = 1.0 / 12.0;
+  sr = fma(-x2, sr, 691.0 / 32760.0);
+  sr = fma(-x2, sr, 1.0 / 132.0);
+  sr = fma(-x2, sr, 1.0 / 240.0);
+  sr = fma(-x2, sr, 1.0 / 252.0);
+  sr = fma(-x2, sr, 1.0 / 120.0);
+  sr = fma(-x2, sr, 1.0 / 12.0);
+  o.xs = xs;
+  o.corr = fma(x2, sr, fma(0.5, xi, shift));
+  return o;
+}
+
 // a * b + c with c a wave-uniform constant held in an SGPR pair
 __device__ __forceinline__ double fma_uc(double a, double b, double c)
 {
@@ -985,11 +1023,11 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
       // selects would run in every slot)
       if (mixed) { asm volatile(""); rt = (c < K) ? rt : rate_bias; }
       rt = fmax(rt, 1e-30);
-      const double ri = fast_rcp(rt);               // ~1 ulp; the exported E is an IEEE sh / rt
+      const PsiRate ps = psi_parts_rate(sh, rt);    // psi(shape) in its split form and 1 / rate, one reciprocal for both
+      const double ri = ps.ri;                      // ~2 ulp; the exported E is an IEEE sh / rt
       double e = sh * ri;                           //   (materialize_es_kernel); this one feeds sums
       if (mixed) { asm volatile(""); e = (c < K) ? e : 0.0; }
       rsum += e; csum[t] += e;
-      const PsiParts ps = psi_parts(sh);
       double wl = ps.xs * exp_neg(ps.corr) * ri;    // exp(psi(shape) - log(rate))
       if (mixed) { asm volatile(""); wl = (c < K || (int32_t)c == a.bias_col) ? wl : ((int32_t)c == a.junk_col ? 1.0 : 0.0); }
       w[t] = wl;
