@@ -55,6 +55,20 @@ def test_create_fails_loudly_without_gpu():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
+def test_page_locked_memory_is_refused_without_gpu():
+    """hpf_host_alloc (ABI v6) says HPF_ERR_NO_DEVICE without a HIP device -- callers fall back to malloc -- and
+    freeing nothing is fine"""
+    import ctypes as C
+    lib = capi.load_library()
+    p = C.c_void_p(1)
+    assert lib.hpf_host_alloc(C.byref(p), 1 << 20) == -2 and not p.value
+    assert lib.hpf_host_alloc(None, 16) == -1
+    assert lib.hpf_host_free(None) == 0
+    with pytest.raises(capi.HpfError):
+        capi.pinned_empty((4, 4))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
 def test_cli_fails_loudly_without_gpu(tmp_path):
     d = tmp_path / "data"
     d.mkdir()
