@@ -452,8 +452,9 @@ __device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], co
 }
 
 // The segments of one wave, over rows of 16-byte pieces: the owner's row in OwnC's layout (LO pieces per
-// lane), the gathered rows in OthC's (LT pieces).  E = OwnC::E element slots are worked on (OthC::E >= E:
-// a shadow row may carry one padding slot more).  W_own / W_oth already point at this lane's first piece.
+// lane), the gathered rows in OthC's (LT pieces).  E = OwnC::E element slots are worked on (OthC::E >= E; the
+// library only instantiates OwnC = OthC -- the two-layout form is what the fp64-shadow experiment of round 4
+// ran on, profiles/r04/experiments.md 1).  W_own / W_oth already point at this lane's first piece.
 template <class OwnC, class OthC, int G, int LO, int LT>
 __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &sr, const unsigned char *W_own,
                                              const unsigned char *W_oth, int lane, bool &underflow)
