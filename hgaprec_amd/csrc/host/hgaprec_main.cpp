@@ -26,6 +26,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <set>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <thread>
 #include <unistd.h>
@@ -109,6 +112,7 @@ struct Driver {
   HeldOut lvalid, ltest;               // this rank's held-out pairs, LOCAL user indices
   std::vector<double> xbuf;            // host staging of the exchange buffer (-comm host)
   SaveBuf save_u[3], save_i[3];        // host copies of an object's shape / rate / expectation while they are written
+  std::set<std::string> part_files;    // (rank 0, several ranks) files whose per-rank parts are lying beside them until the run ends
   std::thread save_prealloc;           // page-locking them (0.2 s per GB) runs beside the start state, not inside the first save
 
   Driver(Env &e, Ratings &r, Comm &c) : env(e), rt(r), comm(c), n(r.n), m(r.m), k(e.k), start(time(0)) {}
@@ -313,26 +317,77 @@ struct Driver {
   // ---- output of sharded objects: every rank writes its rows to a part
   // file, rank 0 concatenates them in rank (= row) order
   std::string part_name(const std::string &path, int r) const { return path + ".part" + std::to_string(r); }
-  void finish_parts(const std::string &path) {
-    if (comm.world == 1) return;
+  // The files of one object at once: one barrier in front, one behind; rank 0 copies the parts of each file
+  // into it on a thread of its own, inside the kernel (copy_file_range) and over the file's old contents --
+  // like the parts themselves, which are kept and rewritten in place until the run ends (finish()): with two ranks
+  // on C2 the copy through a user-space buffer into a truncated file was 7.9 of the run's 17.6 seconds.
+  // errno-style result: 0, or -1 with *bad naming the file that failed.
+  static int concat_parts(const std::string &path, const std::vector<std::string> &parts, std::string *bad) {
+    const int out = ::open(path.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
+    if (out < 0) { *bad = path; return -1; }
+    off_t total = 0;
+    bool in_kernel = true;
+    std::vector<char> buf;
+    for (const std::string &pn : parts) {
+      const int in = ::open(pn.c_str(), O_RDONLY | O_CLOEXEC);
+      struct stat st;
+      if (in < 0 || fstat(in, &st) != 0) { if (in >= 0) ::close(in); ::close(out); *bad = pn; return -1; }   // every rank writes one, even if empty
+      off_t left = st.st_size;
+      while (left > 0 && in_kernel) {
+        const ssize_t got = copy_file_range(in, nullptr, out, nullptr, (size_t)std::min<off_t>(left, (off_t)1 << 30), 0);
+        if (got > 0) { left -= got; total += got; continue; }
+        if (got == 0) { ::close(in); ::close(out); *bad = pn; errno = EIO; return -1; }                 // the part is shorter than it was a moment ago
+        if (errno == EINTR) continue;
+        if (left == st.st_size && (errno == EXDEV || errno == EINVAL || errno == ENOSYS || errno == EOPNOTSUPP)) in_kernel = false;   // this file system cannot: copy by hand
+        else { ::close(in); ::close(out); *bad = path; return -1; }
+      }
+      if (left > 0) {
+        if (buf.empty()) buf.resize((size_t)8 << 20);
+        while (left > 0) {
+          const ssize_t got = ::read(in, buf.data(), (size_t)std::min<off_t>(left, (off_t)buf.size()));
+          if (got < 0 && errno == EINTR) continue;
+          if (got <= 0) { ::close(in); ::close(out); *bad = pn; if (!got) errno = EIO; return -1; }
+          for (ssize_t w = 0; w < got;) {
+            const ssize_t put = ::write(out, buf.data() + w, (size_t)(got - w));
+            if (put < 0 && errno == EINTR) continue;
+            if (put <= 0) { ::close(in); ::close(out); *bad = path; return -1; }
+            w += put;
+          }
+          left -= got; total += got;
+        }
+      }
+      ::close(in);
+    }
+    const bool ok = ftruncate(out, total) == 0;
+    if (::close(out) != 0 || !ok) { *bad = path; return -1; }
+    return 0;
+  }
+  void finish_parts(const std::vector<std::string> &paths) {
+    if (comm.world == 1 || paths.empty()) return;
     comm_check(comm.barrier(), "barrier");
     if (root()) {
-      FILE *out = open_or_die(path, "w");
-      std::vector<char> buf(1 << 20);
-      for (int r = 0; r < comm.world; ++r) {
-        const std::string pn = part_name(path, r);
-        FILE *in = fopen(pn.c_str(), "r");
-        if (!in) io_die("missing part file", pn);           // every rank writes one, even if empty
-        size_t got;
-        while ((got = fread(buf.data(), 1, buf.size(), in)) > 0)
-          if (fwrite(buf.data(), 1, got, out) != got) io_die("cannot write", path);
-        if (ferror(in)) io_die("cannot read", pn);
-        fclose(in);
-        unlink(pn.c_str());
+      std::vector<std::thread> th;
+      std::vector<int> rc(paths.size(), 0), err(paths.size(), 0);
+      std::vector<std::string> bad(paths.size());
+      for (size_t j = 0; j < paths.size(); ++j) {
+        part_files.insert(paths[j]);
+        th.emplace_back([&, j]() {
+          std::vector<std::string> parts;
+          for (int r = 0; r < comm.world; ++r) parts.push_back(part_name(paths[j], r));
+          rc[j] = concat_parts(paths[j], parts, &bad[j]);
+          err[j] = errno;
+        });
       }
-      close_or_die(out, path);
+      for (auto &t : th) t.join();
+      for (size_t j = 0; j < paths.size(); ++j) if (rc[j]) { errno = err[j]; io_die("cannot put the part files together:", bad[j]); }
     }
     comm_check(comm.barrier(), "barrier");
+  }
+  void finish_parts(const std::string &path) { finish_parts(std::vector<std::string>{path}); }
+  void remove_part_files() {                    // end of the run, every rank behind the barrier of finish()
+    for (const std::string &p : part_files)
+      for (int r = 0; r < comm.world; ++r) unlink(part_name(p, r).c_str());
+    part_files.clear();
   }
   std::string my_path(const std::string &path) const { return comm.world == 1 ? path : part_name(path, comm.rank); }
 
@@ -382,8 +437,11 @@ struct Driver {
     for (auto &w : writers) w.join();
     g_clock.acc_join += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
     for (int j = 0; j < 3; ++j) if (failed[j]) io_die("cannot write", dst[j]);
-    if (user_side)
-      for (int j = 0; j < 3; ++j) if (!(j == 1 && vec_rate)) finish_parts(base + suf[j]);
+    if (user_side) {
+      std::vector<std::string> whole;
+      for (int j = 0; j < 3; ++j) if (!(j == 1 && vec_rate)) whole.push_back(base + suf[j]);
+      finish_parts(whole);
+    }
   }
   void save_array(const char *name, hpf_state shape, bool user_side) {
     const uint32_t rows = user_side ? hi - lo : m, row0 = user_side ? lo : 0;
@@ -399,8 +457,8 @@ struct Driver {
         const std::string dst = user_side ? my_path(path) : path;
         if (save_vector(dst, buf.data(), rows, ids.data(), (uint32_t)ids.size(), row0)) io_die("cannot write", dst);
       }
-      if (user_side) finish_parts(path);
     }
+    if (user_side) finish_parts({base + suf[0], base + suf[1], base + suf[2]});
   }
 
   void save_model() {                           // hgaprec.cc:2137-2158
@@ -608,6 +666,7 @@ struct Driver {
     if (h) { hpf_synchronize(h); hpf_destroy(h); h = nullptr; }
     if (root()) { g_clock.totals(iter); g_clock.mark("hpf_destroy"); g_clock.stamp("exit"); }
     comm.barrier();
+    if (root()) remove_part_files();
     comm.close_all();
     exit(code);
   }

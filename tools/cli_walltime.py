@@ -21,6 +21,8 @@ ap.add_argument("--config", default="mid")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--rfreq", type=int, default=10)
 ap.add_argument("--out", default=None)
+ap.add_argument("--ranks", type=int, default=1, help="> 1: also run `-ngpus N -comm host` with all ranks on GPU 0 (what the rank plumbing costs: "
+                                                     "hand-over of the parsed data, part files of the user-side matrices)")
 a = ap.parse_args()
 
 if a.config == "mid":
@@ -50,7 +52,10 @@ res = {"config": a.config, "n": n, "m": m, "nnz": int(u.size), "K": K, "iters": 
 print(f"wrote TSVs ({res['train_tsv_MB']:.0f} MB train) in {time.time() - t0:.1f}s", flush=True)
 exe = Path(__file__).resolve().parent.parent / "hgaprec_amd" / "hgaprec"
 env = dict(os.environ, HPF_CLI_TIMING="1")
-for label, extra in (("text", []), ("cache_write", ["-cache"]), ("cache_read", ["-cache"])):
+cases = [("text", []), ("cache_write", ["-cache"]), ("cache_read", ["-cache"])]
+if a.ranks > 1:
+    cases.append((f"ranks{a.ranks}_one_gpu", ["-ngpus", str(a.ranks), "-comm", "host", "-device", "0"]))
+for label, extra in cases:
     t0 = time.time()
     r = subprocess.run([str(exe), "-dir", str(td), "-n", str(n), "-m", str(m), "-k", str(K), "-hier",
                         "-rfreq", str(a.rfreq), "-max-iterations", str(a.iters)] + extra, cwd=td, capture_output=True, text=True, env=env)
