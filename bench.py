@@ -125,6 +125,20 @@ def parse_counter_csvs(directory, ctr):
     return vals, calv
 
 
+def clean_profiler_env(env):
+    """the environment for a rocprofv3 run of our own, when this process may itself be running under one
+    (`rocprofv3 --kernel-trace --stats -- python bench.py`): the outer tool's settings (ROCPROF_*, ROCP_*,
+    ROCPROFILER_*) and its libraries in LD_PRELOAD are not handed down, so that the inner passes start from
+    what a shell would give them"""
+    out = {k: v for k, v in env.items() if not k.startswith(("ROCPROF_", "ROCP_", "ROCPROFILER_"))}
+    pre = [x for x in out.get("LD_PRELOAD", "").split(":") if x and "rocprofiler" not in x and "rocprof" not in os.path.basename(x)]
+    if pre:
+        out["LD_PRELOAD"] = ":".join(pre)
+    else:
+        out.pop("LD_PRELOAD", None)
+    return out
+
+
 def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
@@ -143,7 +157,7 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
     if not os.path.exists(exe):
         return None, None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="hpf_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = clean_profiler_env(dict(os.environ, TMPDIR="/tmp"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HPF_BENCH_FORCE_DIST"):
         env.pop(k, None)
     per = {0: {}, 1: {}}

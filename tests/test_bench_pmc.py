@@ -49,3 +49,18 @@ def test_lean_is_what_the_profiled_child_runs():
     src = (ROOT / "bench.py").read_text()
     assert "args.no_pmc = args.no_other_configs = args.no_cpu_baseline = True" in src
     assert '"--lean", "--steps", "3", "--warmup", "1"' in src
+
+
+def test_inner_profiler_runs_do_not_inherit_an_outer_one():
+    """bench.py under `rocprofv3 ... -- python bench.py` spawns rocprofv3 passes of its own: they must not inherit the
+    outer tool's settings or its preloaded libraries"""
+    import bench
+    env = {"PATH": "/usr/bin", "TMPDIR": "/tmp", "ROCPROF_OUTPUT_PATH": "/x", "ROCPROF_KERNEL_TRACE": "1",
+           "ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so", "ROCPROFILER_LIBRARY_CTOR": "1",
+           "LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so:/usr/lib/libjemalloc.so:/opt/rocm/lib/librocprofiler-sdk.so",
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    out = bench.clean_profiler_env(env)
+    assert out == {"PATH": "/usr/bin", "TMPDIR": "/tmp", "LD_PRELOAD": "/usr/lib/libjemalloc.so", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env["LD_PRELOAD"] = "/opt/rocm/lib/librocprofiler-sdk.so"
+    assert "LD_PRELOAD" not in bench.clean_profiler_env(env)
+    assert bench.clean_profiler_env({"A": "1"}) == {"A": "1"}
