@@ -139,7 +139,7 @@ def clean_profiler_env(env):
     return out
 
 
-def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
+def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
     slots") over `bench.py --lean --steps 3 --warmup 1` of the same workload, spawned after the
@@ -158,8 +158,10 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=150):
         return None, None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="hpf_pmc_", dir="/tmp")
     env = clean_profiler_env(dict(os.environ, TMPDIR="/tmp"))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HPF_BENCH_FORCE_DIST"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "HPF_BENCH_FORCE_DIST",
+              "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_DEBUG_FILE"):
         env.pop(k, None)
+    env["LOCAL_RANK"] = str(local_rank)          # the child runs on the GPU of the rank that spawned it
     per = {0: {}, 1: {}}
     cal = {}
     t0 = time.perf_counter()
@@ -371,6 +373,13 @@ def main():
                     help="N > 1: ONE all-reduce of [m x ld | ld] after the user half instead of the overlapped pair")
     ap.add_argument("--no-1gpu-reference", action="store_true",
                     help="N > 1: skip rank 0's same-run timing of the whole matrix on one GPU")
+    ap.add_argument("--user-range", type=int, nargs=2, default=None, metavar=("A", "B"),
+                    help="one rank only: generate exactly users [A, B) of the configured matrix (what a rank of a "
+                         "strong-scaling run holds) -- the in-run PMC passes of an N > 1 run profile rank 0's shard with it")
+    ap.add_argument("--split-iteration", action="store_true",
+                    help="one rank only: run the iteration through the calls a rank of a sharded run makes (hpf_iterate_local_items, "
+                         "_users, hpf_iterate_global on a handle created with n_ranks = 2; nothing is reduced) instead of hpf_iterate -- "
+                         "the same kernels on the same lists as rank 0 of an N > 1 run, never a hipGraph replay")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: put every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -430,10 +439,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # rank 0 works alone for a while after the timed region (same-run one-GPU reference, PMC passes over its own
+        # shard, CPU baseline) while the others wait at the last barrier: a generous collective time-out
+        from datetime import timedelta
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(minutes=60))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=timedelta(minutes=60))
     # one explicit (non-default) HIP stream carries the kernels AND orders the
     # all-reduce: torch.distributed synchronises the collective with the
     # *current* torch stream, so the library must launch on that same stream
@@ -441,6 +453,8 @@ def main():
     torch.cuda.set_stream(stream)
 
     strong = world > 1 and not args.weak
+    if (args.user_range or args.split_iteration) and world > 1:
+        raise SystemExit("--user-range / --split-iteration are for a single rank")
     cname = args.config or ("C3" if strong else "C2")
     cfg = dict(synth.CONFIGS[cname])
     if args.scale != 1.0:
@@ -454,7 +468,21 @@ def main():
 
     # ---- synthetic shard, generated on the GPU and left there
     t0 = time.perf_counter()
-    if strong:
+    if args.user_range:
+        # one rank's shard of a strong-scaling run, on its own: the same range of the same matrix (the PMC child of an
+        # N > 1 run: rank 0's item pass walks exactly this work list)
+        n_total = cfg["n"]
+        ua, ub = args.user_range
+        if not (0 <= ua < ub <= n_total):
+            raise SystemExit(f"--user-range {ua} {ub}: outside [0, {n_total}]")
+        deg = synth.degrees(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["seed"], dev)
+        rowptr, col, val = synth.generate_device(n_total, m, cfg["nnz"], cfg["alpha_u"], cfg["alpha_i"],
+                                                 seed=cfg["seed"], device=dev, binary=cfg["binary"],
+                                                 user_range=(ua, ub), deg=deg)
+        del deg
+        row0, state_seed_shift = ua, 0
+        custom = True
+    elif strong:
         # ONE matrix G(seed, n, m, nnz) for every N: the generator is a pure function of
         # (seed, user, draw), so each rank builds exactly its user range of it
         n_total = cfg["n"]
@@ -494,7 +522,7 @@ def main():
     torch.cuda.empty_cache()             # the generator's temporaries go back to the driver: the library allocates with hipMalloc
 
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
-            device=local_rank, stream=stream.cuda_stream, n_ranks=2 if (force_dist and world == 1) else world,
+            device=local_rank, stream=stream.cuda_stream, n_ranks=2 if ((force_dist or args.split_iteration) and world == 1) else world,
             rank=rank, n_users_total=n_total, w_storage=1 if args.w32 else 2 if args.w48 else 0)
     xbuf = None
     if use_dist:
@@ -514,7 +542,11 @@ def main():
     log(f"[rank {rank}] device hand-over: csr {t_upload:.2f}s, state {t_state:.2f}s")
 
     def step():
-        if not use_dist:
+        if args.split_iteration and not use_dist:
+            D.iterate_local_items()
+            D.iterate_local_users()
+            D.iterate_global()
+        elif not use_dist:
             D.iterate(1)
         else:
             # the item shape sums (m*ld doubles) are final after the item-major phi
@@ -624,6 +656,11 @@ def main():
 
     # the timed iterations did the work: mass conservation on the handle that was timed ...
     self_check = mass_check(D, cfg, nnz_loc, val, dev)
+    if args.lean and m > n_loc:
+        # the PMC passes calibrate FETCH_SIZE / WRITE_SIZE on materialize_es_kernel over the LARGER side (known bytes):
+        # the mass check above exported the user side only
+        del_me = D.get_state_device("BETA_SHAPE", dev)
+        del del_me
     ab = D.algorithmic_bytes()
     wi = D.work_info()
     # the ceiling of each phi pass's ACCESS PATTERN on this GPU, measured now: the same work list,
@@ -776,8 +813,16 @@ def main():
             except Exception as ex:
                 out["w48_opt_in"] = {"error": str(ex)}
     cpu_slice = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not force_dist:
-        s_users = int(torch.searchsorted(rowptr, torch.tensor(4_000_000, device=dev)).item()) + 1
+    cpu_note = ""
+    if rank == 0 and not args.no_cpu_baseline:
+        # N = 1: ~4 M nonzeros of C2 (10 s of one core).  Strong scaling (C3 / C5): a contiguous 1 % USER slice of the whole
+        # matrix, taken from the front of rank 0's range, capped at 10 M nonzeros (~25 s at K = 100)
+        target = 4_000_000
+        if strong:
+            target = min(10_000_000, max(1, int(rowptr[min(n_loc, max(1, n_total // 100))].item())))
+            cpu_note = (f"; a contiguous ~1 % user slice of the whole {n_total}-user matrix from the front of rank 0's range "
+                        f"[{ua}, {ub}), all {m} items replicated as on every rank (their sweep is part of the time)")
+        s_users = int(torch.searchsorted(rowptr, torch.tensor(target, device=dev)).item()) + 1
         s_users = min(s_users, n_loc)
         nz = int(rowptr[s_users])
         cpu_slice = (rowptr[: s_users + 1].cpu().numpy(), col[:nz].cpu().numpy().view(np.uint32),
@@ -850,11 +895,18 @@ def main():
         alg_gbs = kbytes / (kms * 1e-3) / 1e9
         traffic = None
         pmc = None
-        traffic_note = "custom workload" if custom else "multi-GPU run" if world > 1 else "--lean / --no-pmc"
-        if world == 1 and not force_dist and not args.no_pmc and not graph:
+        traffic_note = "hipGraph replay: no per-kernel times" if graph else "--lean / --no-pmc"
+        if not args.no_pmc and not graph:
+            # N > 1 (and HPF_BENCH_FORCE_DIST): the child is ONE rank that generates exactly rank 0's user range of the
+            # same matrix and runs whole iterations on it -- the item pass walks the work list rank 0 just timed; the
+            # other ranks wait at the last barrier, rank 0's GPU is otherwise idle
             wl = (["--config", cname] + [x for k in ("n", "m", "nnz", "K") if getattr(args, k) for x in (f"--{k}", str(getattr(args, k)))]
-                  + (["--scale", str(args.scale)] if args.scale != 1.0 else []) + (["--w48"] if args.w48 else []) + (["--w32"] if args.w32 else []))
-            per, cal, traffic_note = pmc_passes(wl, max(n_loc, m), wi["ld"])
+                  + (["--scale", str(args.scale)] if args.scale != 1.0 else []) + (["--w48"] if args.w48 else []) + (["--w32"] if args.w32 else [])
+                  + (["--user-range", str(ua), str(ub)] if (strong or args.user_range) else [])
+                  + (["--split-iteration"] if (use_dist or args.split_iteration) else []))
+            per, cal, traffic_note = pmc_passes(wl, max(n_loc, m), wi["ld"], local_rank=local_rank)
+            if strong and per:
+                traffic_note += f" --user-range {ua} {ub} (rank 0's shard, one rank on rank 0's GPU)"
             if per:
                 fcal = cal.get("fetch_x2_over_known_read") or 1.0
                 fcal = fcal if 0.9 < fcal < 1.25 else 1.0                 # a calibration outside that band is not one
@@ -867,7 +919,7 @@ def main():
                        "launches_averaged": per[1].get("launches"), "calibration": cal, "fetch_calibration_applied": fcal,
                        "formula": "bytes = 2 x FETCH_SIZE x 1024 / fetch_calibration + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE counts 128-B "
                                   "requests at 64 B; Infinity-Cache hits are included: no DRAM-side counter exists)"}
-        if traffic is None and not custom and world == 1:
+        if traffic is None and not custom and world == 1 and not force_dist:
             stored, note2 = measured_traffic(cname, kern)            # labelled fallback: a stored profile of the same kernel source
             if stored:
                 traffic, traffic_note = stored, f"STORED, not this run ({traffic_note}): {note2}"
@@ -933,7 +985,8 @@ def main():
             "per_kernel": per_kernel,
         }
         if cpu_slice is not None:
-            out["cpu_baseline"] = cpu_baseline(cfg, *cpu_slice)
+            out["cpu_baseline"] = cpu_baseline(cfg, *cpu_slice, target_nnz=int(cpu_slice[0][-1]))
+            out["cpu_baseline"]["sample"] += cpu_note
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -274,11 +274,14 @@ struct Driver {
   // over the ranks once -- hpf_start_sums leaves this rank's part in the tail of the exchange buffer
   void start_sums() {
     if (comm.world == 1 || env.vb || !env.bias || env.hier) return;
-    int rc = hpf_start_sums(h);                          // with RCCL the library reduces the tail itself
-    if (rc) die("hpf_start_sums", rc);
-    if (use_rccl) return;
+    // after -resume the tail came with the snapshot, already summed over the ranks: start_sums_pending reads 0 and the
+    // tail must not be reduced a second time (it would come out world x too large -- ADVICE r4)
     hpf_work_info wi;
-    if ((rc = hpf_get_work_info(h, &wi))) die("hpf_get_work_info", rc);
+    int rc = hpf_get_work_info(h, &wi);
+    if (rc) die("hpf_get_work_info", rc);
+    const bool pending = wi.start_sums_pending != 0;
+    if ((rc = hpf_start_sums(h))) die("hpf_start_sums", rc);   // with RCCL the library reduces the tail itself
+    if (use_rccl || !pending) return;
     void *p; size_t cnt;
     hpf_exchange_buffer(h, &p, &cnt);
     xbuf.resize(cnt);

@@ -112,6 +112,9 @@ struct hpf_handle {
   int xfer_mode = 1;               // 0 plain, 1 staged, 2 hipHostRegister
   unsigned xfer_threads = 4;
   bool have_csr = false, derived_dirty = true;
+  bool sums_dirty = true;               // a state array was handed in since the start state's column sums were taken: prepare_derived
+                                        // takes them again.  derived_dirty without it = only W has to be written again (recover_flush):
+                                        // the sums in place -- on several ranks the all-reduced ones -- stay
   uint32_t iterations = 0;
   int phiG = 0, phiR = 0, phiV = 0, swG = 0, swR = 0;
   uint32_t sweep_blocks_max = 2048;     // 8 waves per SIMD (HPF_SWEEP_BLOCKS); 1024 -> 2048: C2 user sweep 0.587 -> 0.544 ms
@@ -167,13 +170,29 @@ RcclApi g_rccl;
 const char *load_rccl()
 {
   if (g_rccl.lib) return nullptr;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // candidates, in order: HPF_RCCL_LIB (a full path: the operator's word wins), the soname as the loader finds it,
+  // $TORCH_LIB_DIR/librccl.so (a box whose only copy ships inside a torch wheel: the C++ CLI has no torch to have
+  // mapped it already), $ROCM_PATH/lib, /opt/rocm/lib
+  std::vector<std::string> names;
+  if (const char *e = getenv("HPF_RCCL_LIB")) if (*e) names.push_back(e);
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  if (const char *e = getenv("TORCH_LIB_DIR")) if (*e) { names.push_back(std::string(e) + "/librccl.so.1"); names.push_back(std::string(e) + "/librccl.so"); }
+  if (const char *e = getenv("ROCM_PATH")) if (*e) { names.push_back(std::string(e) + "/lib/librccl.so.1"); names.push_back(std::string(e) + "/lib/librccl.so"); }
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  names.push_back("/opt/rocm/lib/librccl.so");
   void *lib = nullptr;
   // a copy this process has already mapped (a host application's, torch's) is THE copy:
   // two RCCL builds in one process do not survive each other's teardown
-  for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
-  if (!lib) for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!lib) return "cannot dlopen librccl.so";
+  for (const std::string &n : names) if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
+  if (!lib) for (const std::string &n : names) if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!lib) {
+    static std::string why;
+    const char *de = dlerror();
+    why = std::string("cannot dlopen librccl.so (set HPF_RCCL_LIB to its full path, or TORCH_LIB_DIR to a torch/lib that holds it)") +
+          (de ? std::string(": ") + de : std::string());
+    return why.c_str();
+  }
   RcclApi a; a.lib = lib;
   a.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
   a.CommInitRank = (int (*)(void **, int, IdByValue, int))dlsym(lib, "ncclCommInitRank");
@@ -1230,7 +1249,7 @@ int prepare_derived(hpf_handle *h)
     { int rc0 = recover_flush(h, f[0], f[1]); if (rc0) return rc0; }
   }
   // c[k] = sum_i E[beta_ik]: consumed by the first user sweep
-  {
+  if (h->sums_dirty) {
     Side &s = h->it;
     { int rc0 = refresh_es(h, s); if (rc0) return rc0; }
     const uint32_t nb = s.sweep_blocks;
@@ -1239,7 +1258,7 @@ int prepare_derived(hpf_handle *h)
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(h->ld), dim3(256), 0, h->stream,
                        s.colsum_part, nb, h->ld, s.colsum, h->flags);
   }
-  if (h->jacobi) {      // sum_u E[theta] of the start state: the first item rate uses it
+  if (h->jacobi && h->sums_dirty) {      // sum_u E[theta] of the start state: the first item rate uses it
     h->start_sums_done = false;           // several ranks: this rank's part only, until hpf_start_sums hands it to the exchange
     Side &s = h->u;
     if (!s.have_E) { h->err = "state not initialised: -novb needs THETA_E (the first item rate is built from it)"; return HPF_ERR_STATE; }
@@ -1252,6 +1271,7 @@ int prepare_derived(hpf_handle *h)
   int rc = check_launch(h, "prepare_derived");
   if (rc) return rc;
   h->derived_dirty = false;
+  h->sums_dirty = false;
   return HPF_OK;
 }
 
@@ -1337,9 +1357,11 @@ int phi_items(hpf_handle *h)
   // before every iteration (one stream synchronisation) and repairs the rows first; one rank lets the passes skip and
   // catches up at its next synchronisation point (recover_flush)
   if (h->cfg.n_ranks > 1 && h->wl == WL_P59 && (rc = recover_if_flushed(h))) return rc;
-  if (h->jacobi && h->cfg.n_ranks > 1 && (h->derived_dirty || !h->start_sums_done)) {
+  // (sums_dirty, not derived_dirty: a rank that only has to write its W again after a fall-back from the packed rows keeps
+  // the all-reduced sums it holds and must not enter a collective the other ranks never issue -- ADVICE r4)
+  if (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done)) {
     if (h->comm) { if ((rc = hpf_start_sums(h))) return rc; }
-    else if (h->derived_dirty || !h->start_sums_done) {
+    else {
       h->err = "-novb on several ranks: call hpf_start_sums and sum-all-reduce the last ld doubles of the exchange buffer before the first iteration";
       return HPF_ERR_STATE;
     }
@@ -2093,7 +2115,7 @@ static int set_state_impl(hpf_handle *h, hpf_state which, const double *host, si
     if (kind == 3) s->have_L = true;
   }
   if (kind == 3) s->w_dirty = true;          // Elog of theta/beta or of a bias column
-  if (kind != 0) h->derived_dirty = true;
+  if (kind != 0) h->derived_dirty = h->sums_dirty = true;
   return HPF_OK;
 }
 
@@ -2342,7 +2364,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
     s.w_from_sweep = (f & 256u) != 0;
   }
-  h->derived_dirty = hd.derived_dirty != 0;
+  h->derived_dirty = h->sums_dirty = hd.derived_dirty != 0;
   h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
@@ -2654,6 +2676,7 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->heavy_min_nnz_user = h->u.tiles ? h->u.light_below : 0; out->heavy_min_nnz_item = h->it.tiles ? h->it.light_below : 0;
   out->w_fallbacks = h->fallbacks;
   out->notes = h->notes;
+  out->start_sums_pending = (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done)) ? 1u : 0u;
   out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
   return HPF_OK;
 }

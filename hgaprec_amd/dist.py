@@ -95,9 +95,11 @@ def start_sums(engine, exchange: Exchange | None):
     item rate is built from sum_u E[theta] of the START state, summed over the ranks once.  The engine leaves
     its part in the tail of the exchange buffer (hpf_start_sums); the tail alone is reduced.  Call after the
     start state has been handed over and before the first iterate(); a no-op for every other mode."""
+    wi = engine.work_info()
+    pending = bool(wi.get("start_sums_pending", 1))     # 0 after a snapshot load: the tail came with it, already reduced
     engine.start_sums()
-    if exchange is not None:
-        exchange.allreduce_tail(engine.work_info()["ld"])
+    if exchange is not None and pending:
+        exchange.allreduce_tail(wi["ld"])
 
 
 def iterate(engine, exchange: Exchange | None, n_iters: int = 1):

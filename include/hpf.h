@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 6
+#define HPF_ABI_VERSION 7
 
 typedef struct hpf_handle hpf_handle;
 
@@ -248,8 +248,10 @@ int  hpf_iterate_global(hpf_handle *h);
  * rank's part of that sum in the tail of the exchange buffer (its last `ld` doubles,
  * hpf_work_info.ld).  With hpf_comm_init done it also all-reduces the tail itself (and hpf_iterate
  * calls it on its own); otherwise the caller sum-all-reduces those ld doubles in place, like the
- * per-iteration exchange.  Call it after the last hpf_set_state / hpf_snapshot_load and before the
- * first hpf_iterate_local_*: iterating without it returns HPF_ERR_STATE.  A no-op elsewhere. */
+ * per-iteration exchange -- but ONLY when hpf_work_info.start_sums_pending read 1 before the call: after
+ * hpf_snapshot_load the tail is the reduced sum already (v7).  Call it after the last hpf_set_state /
+ * hpf_snapshot_load and before the first hpf_iterate_local_*: iterating without it returns
+ * HPF_ERR_STATE.  A no-op elsewhere. */
 int  hpf_start_sums(hpf_handle *h);
 
 /* The library can run that all-reduce itself: RCCL is dlopen'ed on first use
@@ -339,6 +341,14 @@ typedef struct {
                                      /* state turned up that p59 cannot hold (w_layout then reads 4); 0 or 1            */
   uint32_t notes;                    /* bit 0 / 1: the user / item side was left row-major because the device is too     */
                                      /* small for the tiling's temporaries; bit 2 / 3: because their allocation failed   */
+  /* ABI v7 */
+  uint32_t start_sums_pending;       /* 1: -novb on several ranks and the tail of the exchange buffer does not hold the   */
+                                     /* all-reduced sum_u E[theta] of the start state yet -- hpf_start_sums will leave    */
+                                     /* this rank's PART there and a caller that owns the exchange has to sum-all-reduce  */
+                                     /* it.  0 after hpf_snapshot_load of a state saved between iterations: the tail came */
+                                     /* with the snapshot, already reduced; reducing it again would multiply it by the    */
+                                     /* number of ranks.  Read it BEFORE calling hpf_start_sums.                          */
+  uint32_t reserved0;
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 

@@ -444,6 +444,45 @@ static void gp_swap(gp *g)           /* gpbase.hh:240-246,571-577,897-903 */
   gp_set_to_prior(g);
 }
 
+/* GPMatrix::set_prior_rate gpbase.hh:163-173: rnext[n,:] = ev[n] (D2Array::set_elements(row, v), matrix.hh:946-951,
+   which OVERWRITES the rprior the row held), and the E / E[log] of the row's rate prior are kept for the ELBO */
+static void gp_set_prior_rate(gp *g, const double *ev, const double *elogv)
+{
+  for (uint32_t n = 0; n < g->n; ++n) {
+    for (uint32_t k = 0; k < g->k; ++k) g->rnext[(size_t)n * g->k + k] = ev[n];
+    g->hier_rprior[n] = ev[n]; g->hier_log_rprior[n] = elogv[n];
+  }
+  g->hier = 1;
+}
+
+/* GPMatrix::update_rate_next(const Array &u) gpbase.hh:218-223: _rnext.add_slice(i, u) for every row
+   (matrix.hh:1060-1067); GPMatrixGR::update_rate_next gpbase.hh:560-564 and GPArray::update_rate_next 884-889:
+   _rnext += u (D1Array::operator+=, matrix.hh:464-472) */
+static void gp_update_rate_next(gp *g, const double *u)
+{
+  if (g->global_rate) { for (uint32_t k = 0; k < g->k; ++k) g->rnext[k] += u[k]; return; }
+  for (uint32_t i = 0; i < g->n; ++i)
+    for (uint32_t k = 0; k < g->k; ++k) g->rnext[(size_t)i * g->k + k] += u[k];
+}
+
+/* GPArray::update_rate_next(const Array &u) gpbase.hh:884-889 on an n-vector (k == 1): _rnext += u */
+static void gp_array_update_rate_next(gp *g, const double *u)
+{
+  for (uint32_t n = 0; n < g->n; ++n) g->rnext[n] += u[n];
+}
+
+/* GPArray::update_shape_next(double v) gpbase.hh:877-882 */
+static void gp_array_update_shape_next(gp *g, double v)
+{
+  for (uint32_t n = 0; n < g->n; ++n) g->snext[n] += v;
+}
+
+/* GPMatrix::update_rate_next_all(uint32_t k, double v) gpbase.hh:225-231, k == 0 */
+static void gp_update_rate_next_all(gp *g, double v)
+{
+  for (uint32_t i = 0; i < g->n; ++i) g->rnext[(size_t)i * g->k] += v;
+}
+
 static int g_parallel_sweeps = 0;   /* set only inside orc_model_iterate_all_cores */
 
 static void gp_compute_expectations(gp *g) /* gpbase.hh:248-262,579-598,912-925 */
@@ -544,6 +583,31 @@ struct orc_model {
   int novb;                /* Env::vb == false (-novb); read by vb_bias() only */
 };
 
+/* TEST ENTRY (tests/test_oracle_pins.py): the sweep steps above, run on arrays handed in, so that the functions the
+   model's iteration calls are the ones held against the reference's own D2Array / D1Array code (oracle/_ref/refpart
+   rows, tests/golden/rows.json).  mode 0: GPMatrix (set_prior_rate, update_rate_next, swap); 1: GPMatrixGR
+   (update_rate_next, swap); 2: GPArray (update_shape_next(v), update_rate_next(u[n]), swap); 3: bias GPMatrix
+   (update_rate_next_all(0, v), swap).  snext_in: rows*k shape accumulators (the phi sums + prior).  Outputs: scurr,
+   rcurr (rows*k; mode 1: rcurr is k long), and the refilled snext / rnext. */
+void orc_test_sweep_steps(int mode, uint32_t rows, uint32_t k, const double *snext_in, const double *ev,
+                          const double *u, double v, double *scurr, double *rcurr, double *snext, double *rnext)
+{
+  gp g;
+  gp_init(&g, rows, k, mode == 1);
+  gp_set_to_prior(&g);
+  memcpy(g.snext, snext_in, sizeof(double) * (size_t)rows * k);
+  if (mode == 0) { gp_set_prior_rate(&g, ev, ev); gp_update_rate_next(&g, u); }
+  else if (mode == 1) gp_update_rate_next(&g, u);
+  else if (mode == 2) { gp_array_update_shape_next(&g, v); gp_array_update_rate_next(&g, u); }
+  else gp_update_rate_next_all(&g, v);
+  gp_swap(&g);
+  memcpy(scurr, g.scurr, sizeof(double) * (size_t)rows * k);
+  memcpy(rcurr, g.rcurr, sizeof(double) * g.rsize);
+  memcpy(snext, g.snext, sizeof(double) * (size_t)rows * k);
+  memcpy(rnext, g.rnext, sizeof(double) * g.rsize);
+  gp_free(&g);
+}
+
 orc_model *orc_model_new(uint32_t n, uint32_t m, uint32_t K, int hier, int bias,
                          int binary)
 {
@@ -632,9 +696,9 @@ static void sweep_nonzeros(orc_model *M)
 
 static void bias_sweeps(orc_model *M)   /* hgaprec.cc:1388-1396 / 1262-1268 */
 {
-  for (uint32_t i = 0; i < M->n; ++i) M->ubias.rnext[i] += M->m; /* gpbase.hh:225-231 */
+  gp_update_rate_next_all(&M->ubias, M->m);
   gp_swap(&M->ubias); gp_compute_expectations(&M->ubias);
-  for (uint32_t i = 0; i < M->m; ++i) M->ibias.rnext[i] += M->n;
+  gp_update_rate_next_all(&M->ibias, M->n);
   gp_swap(&M->ibias); gp_compute_expectations(&M->ibias);
 }
 
@@ -645,40 +709,28 @@ static void iterate_hier(orc_model *M)  /* hgaprec.cc:1340-1414 */
   /* B: hgaprec.cc:1370-1378 */
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->beta, M->tmpK);
-  for (uint32_t n = 0; n < M->n; ++n) {          /* set_prior_rate gpbase.hh:163-173 */
-    for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] = M->xi.Ev[n];
-    M->theta.hier_rprior[n] = M->xi.Ev[n]; M->theta.hier_log_rprior[n] = M->xi.Elogv[n];
-  }
-  M->theta.hier = 1;
-  for (uint32_t n = 0; n < M->n; ++n)            /* update_rate_next gpbase.hh:218-223 */
-    for (uint32_t k = 0; k < K; ++k) M->theta.rnext[(size_t)n * K + k] += M->tmpK[k];
+  gp_set_prior_rate(&M->theta, M->xi.Ev, M->xi.Elogv);
+  gp_update_rate_next(&M->theta, M->tmpK);
   gp_swap(&M->theta); gp_compute_expectations(&M->theta);
   /* C: hgaprec.cc:1380-1386 */
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->theta, M->tmpK);
-  for (uint32_t i = 0; i < M->m; ++i) {
-    for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] = M->eta.Ev[i];
-    M->beta.hier_rprior[i] = M->eta.Ev[i]; M->beta.hier_log_rprior[i] = M->eta.Elogv[i];
-  }
-  M->beta.hier = 1;
-  for (uint32_t i = 0; i < M->m; ++i)
-    for (uint32_t k = 0; k < K; ++k) M->beta.rnext[(size_t)i * K + k] += M->tmpK[k];
+  gp_set_prior_rate(&M->beta, M->eta.Ev, M->eta.Elogv);
+  gp_update_rate_next(&M->beta, M->tmpK);
   gp_swap(&M->beta); gp_compute_expectations(&M->beta);
   /* D */
   if (M->bias) bias_sweeps(M);
   /* E: hgaprec.cc:1398-1405 */
   memset(M->tmpN, 0, sizeof(double) * M->n);
   gp_sum_cols(&M->theta, M->tmpN);
-  { double v = K * M->xi.sprior;                  /* _k * _thetarate.sprior() */
-    for (uint32_t n = 0; n < M->n; ++n) M->xi.snext[n] += v;      /* gpbase.hh:877-882 */
-    for (uint32_t n = 0; n < M->n; ++n) M->xi.rnext[n] += M->tmpN[n]; }
+  gp_array_update_shape_next(&M->xi, K * M->xi.sprior);          /* _k * _thetarate.sprior() */
+  gp_array_update_rate_next(&M->xi, M->tmpN);
   gp_swap(&M->xi); gp_compute_expectations(&M->xi);
   /* F: hgaprec.cc:1407-1414 */
   memset(M->tmpN, 0, sizeof(double) * M->m);
   gp_sum_cols(&M->beta, M->tmpN);
-  { double v = K * M->eta.sprior;
-    for (uint32_t i = 0; i < M->m; ++i) M->eta.snext[i] += v;
-    for (uint32_t i = 0; i < M->m; ++i) M->eta.rnext[i] += M->tmpN[i]; }
+  gp_array_update_shape_next(&M->eta, K * M->eta.sprior);
+  gp_array_update_rate_next(&M->eta, M->tmpN);
   gp_swap(&M->eta); gp_compute_expectations(&M->eta);
 }
 
@@ -691,12 +743,12 @@ static void iterate_flat_bias_novb(orc_model *M)
   sweep_nonzeros(M);
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->beta, M->tmpK);                                   /* 1278-1280 */
-  for (uint32_t k = 0; k < K; ++k) M->theta.rnext[k] += M->tmpK[k];
+  gp_update_rate_next(&M->theta, M->tmpK);
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->theta, M->tmpK);                                  /* 1281-1283: the OLD E[theta] */
-  for (uint32_t k = 0; k < K; ++k) M->beta.rnext[k] += M->tmpK[k];
-  for (uint32_t i = 0; i < M->n; ++i) M->ubias.rnext[i] += M->m;    /* 1285-1286 */
-  for (uint32_t i = 0; i < M->m; ++i) M->ibias.rnext[i] += M->n;
+  gp_update_rate_next(&M->beta, M->tmpK);
+  gp_update_rate_next_all(&M->ubias, M->m);                         /* 1285-1286 */
+  gp_update_rate_next_all(&M->ibias, M->n);
   gp_swap(&M->theta); gp_swap(&M->beta); gp_swap(&M->ubias); gp_swap(&M->ibias);   /* 1288-1291 */
   gp_compute_expectations(&M->theta); gp_compute_expectations(&M->beta);            /* 1293-1296 */
   gp_compute_expectations(&M->ubias); gp_compute_expectations(&M->ibias);
@@ -709,11 +761,11 @@ static void iterate_flat(orc_model *M)  /* vb(): hgaprec.cc:927-956 ; vb_bias():
   sweep_nonzeros(M);
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->beta, M->tmpK);
-  for (uint32_t k = 0; k < K; ++k) M->theta.rnext[k] += M->tmpK[k];  /* gpbase.hh:558-562 */
+  gp_update_rate_next(&M->theta, M->tmpK);                           /* gpbase.hh:558-562 */
   gp_swap(&M->theta); gp_compute_expectations(&M->theta);
   memset(M->tmpK, 0, sizeof(double) * K);
   gp_sum_rows(&M->theta, M->tmpK);
-  for (uint32_t k = 0; k < K; ++k) M->beta.rnext[k] += M->tmpK[k];
+  gp_update_rate_next(&M->beta, M->tmpK);
   gp_swap(&M->beta); gp_compute_expectations(&M->beta);
   if (M->bias) bias_sweeps(M);
 }

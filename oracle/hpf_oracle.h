@@ -45,6 +45,9 @@ double orc_psi(double x);
 double orc_logsum(const double *x, uint32_t n);
 /* D1Array<T>::sum (matrix.hh:327-335): the left-to-right sum the row / column sums are made of */
 double orc_sum_strided(const double *d, uint32_t n, size_t stride);
+/* test entry: the model's own sweep steps on caller arrays (see hpf_oracle.c) */
+void orc_test_sweep_steps(int mode, uint32_t rows, uint32_t k, const double *snext_in, const double *ev,
+                          const double *u, double v, double *scurr, double *rcurr, double *snext, double *rnext);
 void   orc_lognormalize(double *x, uint32_t n);
 
 /* ---- ratings store (ratings.cc:63-119) ---- */

@@ -155,6 +155,24 @@ def seq_sum(x, stride=1, n=None):
     return lib().orc_sum_strided(a.ctypes.data_as(C.POINTER(C.c_double)), n, stride)
 
 
+def sweep_steps(mode, snext_in, ev, u, v=0.0):
+    """the model's own sweep steps (gp_set_prior_rate / gp_update_rate_next / gp_array_* / gp_swap of hpf_oracle.c) on
+    caller arrays -> (scurr, rcurr, snext, rnext); mode as in orc_test_sweep_steps"""
+    L = lib()
+    snext_in = np.ascontiguousarray(snext_in, np.float64)
+    rows, k = (snext_in.shape[0], 1) if snext_in.ndim == 1 else snext_in.shape
+    ev = np.ascontiguousarray(ev, np.float64); u = np.ascontiguousarray(u, np.float64)
+    nr = k if mode == 1 else rows * k
+    scurr, snext = np.empty(rows * k), np.empty(rows * k)
+    rcurr, rnext = np.empty(nr), np.empty(nr)
+    dp = C.POINTER(C.c_double)
+    L.orc_test_sweep_steps.restype = None
+    L.orc_test_sweep_steps.argtypes = [C.c_int, C.c_uint32, C.c_uint32, dp, dp, dp, C.c_double, dp, dp, dp, dp]
+    L.orc_test_sweep_steps(mode, rows, k, snext_in.ctypes.data_as(dp), ev.ctypes.data_as(dp), u.ctypes.data_as(dp), float(v),
+                           scurr.ctypes.data_as(dp), rcurr.ctypes.data_as(dp), snext.ctypes.data_as(dp), rnext.ctypes.data_as(dp))
+    return scurr, rcurr, snext, rnext
+
+
 def logsum(x):
     a = np.ascontiguousarray(x, dtype=np.float64)
     return lib().orc_logsum(a.ctypes.data_as(C.POINTER(C.c_double)), a.size)

@@ -24,6 +24,18 @@
 //       in : u32 n, u32 maxn, f64 fill, f64 x[n]
 //       out: f64 D1Array::sum(), f64 D1Array::sum(maxn), then a D2Array(3, n) after
 //            set_elements(fill) (3n f64), then x after zero() (n f64)
+//   refpart rows <in.bin> <out.bin>
+//       the matrix.hh calls the sweep methods of gpbase.hh are made of (gpbase.hh itself needs GSL and is not
+//       compiled: the ORDER of the calls below is this driver's restatement of gpbase.hh:149-246,560-578,
+//       858-903, the arithmetic is the reference's own D2Array / D1Array code)
+//       in : u32 mode, u32 rows, u32 k, f64 sprior, f64 rprior, f64 v,
+//            f64 snext[rows*k], f64 ev[rows], f64 u[mode == 2 ? rows : k]
+//       mode 0 (GPMatrix): rnext.set_elements(n, ev[n]) for every n; rnext.add_slice(i, u) for every i;
+//                          scurr.swap(snext); rcurr.swap(rnext); snext/rnext.set_elements(prior)
+//       mode 1 (GPMatrixGR): D1Array rnext += u; swaps; set_elements(prior)
+//       mode 2 (GPArray):  snext[n] += v; D1Array rnext += u; swaps; set_elements(prior)
+//       mode 3 (bias GPMatrix, k == 1): rnext[i][0] += v; swaps; set_elements(prior)
+//       out: scurr, rcurr, snext, rnext (row-major; modes 1: rcurr / rnext are k long)
 #include <map>
 #include <stdint.h>
 #include <stdio.h>
@@ -96,6 +108,64 @@ static int cmd_arrays(const char *in, const char *out) {
   return 0;
 }
 
+static void wr2(FILE *g, D2Array<double> &M, uint32_t rows, uint32_t k) {
+  const double **d = M.const_data();
+  for (uint32_t i = 0; i < rows; ++i) fwrite(d[i], 8, k, g);
+}
+
+static int cmd_rows(const char *in, const char *out) {
+  FILE *f = fopen(in, "rb"), *g = fopen(out, "wb");
+  uint32_t mode, rows, k; double sprior, rprior, v;
+  rd(f, &mode, 4); rd(f, &rows, 4); rd(f, &k, 4); rd(f, &sprior, 8); rd(f, &rprior, 8); rd(f, &v, 8);
+  if (mode == 0 || mode == 3) {
+    D2Array<double> scurr(rows, k), snext(rows, k), rcurr(rows, k), rnext(rows, k);
+    scurr.set_elements(sprior); rcurr.set_elements(rprior);
+    snext.set_elements(sprior); rnext.set_elements(rprior);             // set_to_prior
+    double **sd = snext.data();
+    for (uint32_t i = 0; i < rows; ++i) rd(f, sd[i], 8 * (size_t)k);    // the phi sums already added
+    Array ev(rows); rd(f, ev.data(), 8 * (size_t)rows);
+    Array u(k); rd(f, u.data(), 8 * (size_t)k);
+    if (mode == 0) {
+      for (uint32_t n = 0; n < rows; ++n) rnext.set_elements(n, ev[n]);
+      for (uint32_t i = 0; i < rows; ++i) rnext.add_slice(i, u);
+    } else {
+      double **r = rnext.data();
+      for (uint32_t i = 0; i < rows; ++i) r[i][0] += v;
+    }
+    scurr.swap(snext); rcurr.swap(rnext);
+    snext.set_elements(sprior); rnext.set_elements(rprior);
+    wr2(g, scurr, rows, k); wr2(g, rcurr, rows, k); wr2(g, snext, rows, k); wr2(g, rnext, rows, k);
+  } else if (mode == 1) {
+    D2Array<double> scurr(rows, k), snext(rows, k);
+    Array rcurr(k), rnext(k);
+    scurr.set_elements(sprior); rcurr.set_elements(rprior);
+    snext.set_elements(sprior); rnext.set_elements(rprior);
+    double **sd = snext.data();
+    for (uint32_t i = 0; i < rows; ++i) rd(f, sd[i], 8 * (size_t)k);
+    Array ev(rows); rd(f, ev.data(), 8 * (size_t)rows);
+    Array u(k); rd(f, u.data(), 8 * (size_t)k);
+    rnext += u;
+    scurr.swap(snext); rcurr.swap(rnext);
+    snext.set_elements(sprior); rnext.set_elements(rprior);
+    wr2(g, scurr, rows, k); fwrite(rcurr.data(), 8, k, g); wr2(g, snext, rows, k); fwrite(rnext.data(), 8, k, g);
+  } else {
+    Array scurr(rows), snext(rows), rcurr(rows), rnext(rows);
+    scurr.set_elements(sprior); rcurr.set_elements(rprior);
+    snext.set_elements(sprior); rnext.set_elements(rprior);
+    rd(f, snext.data(), 8 * (size_t)rows);
+    Array ev(rows); rd(f, ev.data(), 8 * (size_t)rows);
+    Array u(rows); rd(f, u.data(), 8 * (size_t)rows);
+    for (uint32_t n = 0; n < rows; ++n) snext[n] += v;
+    rnext += u;
+    scurr.swap(snext); rcurr.swap(rnext);
+    snext.set_elements(sprior); rnext.set_elements(rprior);
+    fwrite(scurr.data(), 8, rows, g); fwrite(rcurr.data(), 8, rows, g);
+    fwrite(snext.data(), 8, rows, g); fwrite(rnext.data(), 8, rows, g);
+  }
+  fclose(f); fclose(g);
+  return 0;
+}
+
 static int cmd_save(const char *in, const char *mt, const char *vt) {
   FILE *f = fopen(in, "rb");
   uint32_t rows, cols, nids;
@@ -153,8 +223,9 @@ int main(int argc, char **argv) {
   if (argc >= 4 && !strcmp(argv[1], "softmax")) return cmd_softmax(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "accumulate")) return cmd_accumulate(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "arrays")) return cmd_arrays(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "rows")) return cmd_rows(argv[2], argv[3]);
   if (argc >= 5 && !strcmp(argv[1], "save")) return cmd_save(argv[2], argv[3], argv[4]);
   if (argc >= 2 && !strcmp(argv[1], "env")) return cmd_env(argc - 2, argv + 2);
-  fprintf(stderr, "usage: refpart softmax|accumulate|arrays|save|env ...\n");
+  fprintf(stderr, "usage: refpart softmax|accumulate|arrays|rows|save|env ...\n");
   return 2;
 }

@@ -9,6 +9,7 @@ the reference needs GSL (absent here), so there are no end-to-end fixtures:
 see DESIGN.md "Oracle".
 
     python tests/golden/make_golden.py        # rewrites tests/golden/
+    python tests/golden/make_golden.py rows   # only the named fixture files
 """
 from __future__ import annotations
 
@@ -107,6 +108,39 @@ def arrays_cases():
                       "zero": hexl(raw[2 + 3 * n:2 + 4 * n])})
     return {"source": "D1Array<double>::sum matrix.hh:327-335, zero 200-203, D2Array<double>::set_elements 930-936",
             "cases": cases}
+
+
+def rows_cases():
+    """the matrix.hh calls the sweep methods of gpbase.hh are made of -- D2Array::set_elements(row, v) (946-951),
+    add_slice with the same vector on every row (1060-1067), D1Array::operator+= (464-472), D2Array / D1Array::swap
+    (971-977, 449-454), set_elements(prior) -- run by the reference's own containers in the order gpbase.hh calls
+    them (the order is the harness's: gpbase.hh needs GSL).  Pins the oracle's gp_set_prior_rate /
+    gp_update_rate_next / gp_array_* / gp_swap, bit for bit."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for mode, rows, k in ((0, 7, 5), (0, 3, 100), (0, 1, 1), (1, 6, 4), (1, 2, 100), (2, 9, 1), (2, 1, 1), (3, 8, 1)):
+        sprior, rprior = 0.3, 0.3
+        v = float(0.3 * 20) if mode == 2 else float(200 + rows) if mode == 3 else 0.0
+        snext = 0.3 + rng.gamma(0.5, 2.0, size=(rows, k)) * 10.0 ** rng.integers(-6, 4, size=(rows, k))
+        ev = rng.gamma(2.0, 0.1, size=rows)
+        u = rng.gamma(1.0, 50.0, size=rows if mode == 2 else k)
+        with tempfile.TemporaryDirectory() as td:
+            fin, fout = Path(td) / "in.bin", Path(td) / "out.bin"
+            with open(fin, "wb") as f:
+                f.write(struct.pack("<IIIddd", mode, rows, k, sprior, rprior, v))
+                f.write(snext.astype("<f8").tobytes()); f.write(ev.astype("<f8").tobytes()); f.write(u.astype("<f8").tobytes())
+            subprocess.run([str(REFPART), "rows", str(fin), str(fout)], check=True)
+            raw = np.fromfile(fout, "<f8")
+        ns, nr = rows * k, (k if mode == 1 else rows * k)
+        assert raw.size == 2 * ns + 2 * nr
+        cases.append({"mode": mode, "rows": rows, "k": k, "sprior": float(sprior).hex(), "rprior": float(rprior).hex(),
+                      "v": float(v).hex(), "snext_in": hexl(snext), "ev": hexl(ev), "u": hexl(u),
+                      "scurr": hexl(raw[:ns]), "rcurr": hexl(raw[ns:ns + nr]),
+                      "snext": hexl(raw[ns + nr:2 * ns + nr]), "rnext": hexl(raw[2 * ns + nr:])})
+    return {"source": "D2Array<double>::set_elements(row, v) matrix.hh:946-951, add_slice 1060-1067, swap 971-977; "
+                      "D1Array<double>::operator+= 464-472, swap 449-454, set_elements 193-197 -- called in the order of "
+                      "gpbase.hh:149-246 (GPMatrix, mode 0; update_rate_next_all, mode 3), 522-578 (GPMatrixGR, mode 1), "
+                      "858-903 (GPArray, mode 2)", "cases": cases}
 
 
 def save_cases():
@@ -228,8 +262,11 @@ def main():
     if not REFPART.exists():
         sys.exit("oracle/_ref/refpart missing: run `make -C oracle ref` where /root/reference exists")
     GOLD.mkdir(parents=True, exist_ok=True)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for name, fn in (("softmax", softmax_cases), ("accumulate", accumulate_cases), ("arrays", arrays_cases),
-                     ("save", save_cases), ("env", env_cases)):
+                     ("rows", rows_cases), ("save", save_cases), ("env", env_cases)):
+        if only and name not in only:
+            continue
         (GOLD / f"{name}.json").write_text(json.dumps(fn(), indent=1))
         print("wrote", GOLD / f"{name}.json")
 

@@ -264,6 +264,47 @@ def test_checkpoint_and_resume_two_ranks(tmp_path):
     assert (outa / "precision.txt").read_text() == (outb / "precision.txt").read_text()
 
 
+def test_resume_of_vb_bias_novb_on_two_ranks_keeps_the_reduced_start_sums(tmp_path):
+    """`-bias -novb` without `-hier` on two ranks, `-comm host`.  The snapshot a rank reloads carries
+    the ALL-REDUCED sum_u E[theta] in the tail of its exchange buffer; reducing that tail once more on resume made the
+    first resumed item rate world x too large.  hpf_work_info.start_sums_pending (ABI v7) now says whether the tail
+    still has to be reduced.  vb_bias() has no -max-iterations (hgaprec.cc:1219-1319): the first run goes to its stop
+    rule and leaves its last checkpoint (every 7 iterations) a few iterations before the end; the resumed run must
+    stop at the same iteration with the same files."""
+    n, m, K = 300, 200, 5
+    data = tmp_path / "data"
+    write_dataset(data, n, m, 9000, seed=17)
+    base = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-seed", "7", "-rfreq", "10", "-bias", "-novb",
+            "-ngpus", "2", "-device", "0", "-comm", "host"]
+    a, b = tmp_path / "straight", tmp_path / "resumed"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([str(EXE)] + base, cwd=a, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([str(EXE)] + base + ["-checkpoint", "7"], cwd=b, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outa = [p for p in a.iterdir() if p.is_dir()][0]
+    outb = [p for p in b.iterdir() if p.is_dir()][0]
+    assert (outb / "checkpoint.r0of2.bin").exists() and (outb / "checkpoint.r1of2.bin").exists()
+    sa = series(outa / "validation.txt")
+    stop_iter = sa[-1][0]
+    assert stop_iter >= 40 and stop_iter % 7 != 0          # so the checkpoint is older than the last iteration
+    before = series(outb / "validation.txt")
+    assert before == sa
+    r = subprocess.run([str(EXE)] + base + ["-checkpoint", "7", "-resume"], cwd=b, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    said = r.stderr + (outb / "infer.log").read_text()
+    assert "resumed from" in said and f"at iteration {stop_iter // 7 * 7 + 1}" in said
+    sb = series(outb / "validation.txt")
+    # the resumed run appended the report steps it repeated: they must be the straight run's, digit for digit
+    extra = sb[len(before):]
+    assert extra and extra[-1][0] == stop_iter
+    tail = {x[0]: x for x in sa}
+    assert all((x[0], x[1], x[2]) == (tail[x[0]][0], tail[x[0]][1], tail[x[0]][2]) for x in extra)
+    for nm in ("theta", "beta", "thetabias", "betabias"):
+        for suf in ("", "_shape", "_rate"):
+            assert (outa / f"{nm}{suf}.tsv").read_text() == (outb / f"{nm}{suf}.tsv").read_text(), nm + suf
+
+
 def test_dataset_cache_runs_are_identical(tmp_path):
     """-cache (extension): first run parses the TSVs and writes the binary image,
     the second loads it; every output file must be byte-identical (same CSR,

@@ -335,6 +335,15 @@ def test_two_ranks_on_one_gpu_bench_strong_scaling_over_gloo(single):
     pr = d["per_rank"]
     assert pr[0]["users"] + pr[1]["users"] == n and abs(pr[0]["nnz"] - pr[1]["nnz"]) < 0.05 * int(rp[-1])
     assert all(x["phi_item_ms"] > 0 and x["exchange_wait_ms"] >= 0 for x in pr)
+    # the N > 1 line stands on its own: a MEMORY-SIDE roofline from PMC counters read in this run over rank
+    # 0's own shard, and the CPU oracle timed on a 1 % user slice of the whole matrix
+    rf = d["roofline"]
+    assert rf["frac_basis"].startswith("memory-side"), rf
+    assert rf["traffic"] and 0 < rf["frac"] <= 1.0 and "--user-range" in rf["traffic_source"]
+    assert rf["pmc"]["per_launch_bytes"]["phi_item"] > 0 and 0.9 < rf["pmc"]["fetch_calibration_applied"] < 1.25
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and "1 % user slice" in cb["sample"]
+    assert cb["all_cores"]["value"] > 0
 
 
 def test_one_gpu_bench_takes_the_distributed_path():
@@ -342,12 +351,17 @@ def test_one_gpu_bench_takes_the_distributed_path():
     overlapped all-reduces) on one rank -- HPF_BENCH_FORCE_DIST=1 -- at 1 % of C2"""
     env = dict(os.environ, HPF_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.01",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.01"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["replica_check"] == "ok" and d["self_check"]["ok"]
-    assert d["roofline"]["traffic"] is None and "per_rank" in d
+    assert "per_rank" in d
+    # the distributed path's line passes the N = 1 rules: memory-side roofline from this run's counters + CPU baseline
+    rf = d["roofline"]
+    assert rf["frac_basis"].startswith("memory-side") and rf["traffic"] and 0 < rf["frac"] <= 1.0, rf
+    assert "this run" in rf["traffic_source"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
     # a real (one-rank) RCCL communicator: its version and what its own log said
     assert d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["version"]
     assert d["rccl"]["log"].get("lines", 0) > 0, d["rccl"]

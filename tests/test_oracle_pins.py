@@ -180,6 +180,57 @@ def test_sum_set_elements_zero_golden_bit_exact(orc):
         assert np.all(unhex(c["zero"]) == 0.0)
 
 
+def test_sweep_steps_golden_bit_exact(orc):
+    """the rest of the pinnable set: D2Array::set_elements(row, v), add_slice of one vector on every row,
+    D1Array::operator+=, swap + set_elements(prior) -- the reference's own containers, called in gpbase.hh's order by
+    oracle/ref_harness.cc -- against the very functions the oracle's iteration runs (orc_test_sweep_steps), bit for bit.
+    What this does NOT pin is that gpbase.hh calls them in that order: that translation unit needs GSL."""
+    d = json.loads((GOLD / "rows.json").read_text())
+    modes = set()
+    for c in d["cases"]:
+        rows, k, mode = c["rows"], c["k"], c["mode"]
+        sn = unhex(c["snext_in"]).reshape(rows, k)
+        got = orc.sweep_steps(mode, sn, unhex(c["ev"]), unhex(c["u"]), float.fromhex(c["v"]))
+        for g, nm in zip(got, ("scurr", "rcurr", "snext", "rnext")):
+            assert np.array_equal(g, unhex(c[nm])), (mode, rows, k, nm)
+        # and what the values ARE: the rate row is E[xi_row] + colsum (the 0.3 it held is overwritten, gpbase.hh:168)
+        if mode == 0:
+            assert np.array_equal(unhex(c["rcurr"]).reshape(rows, k), unhex(c["ev"])[:, None] + unhex(c["u"])[None, :])
+        if mode == 1:
+            assert np.array_equal(unhex(c["rcurr"]), 0.3 + unhex(c["u"]))
+        if mode == 2:
+            assert np.array_equal(unhex(c["scurr"]), sn.ravel() + float.fromhex(c["v"]))
+            assert np.array_equal(unhex(c["rcurr"]), 0.3 + unhex(c["u"]))
+        if mode == 3:
+            assert np.array_equal(unhex(c["rcurr"]), np.full(rows, 0.3) + float.fromhex(c["v"]))
+        assert np.all(unhex(c["snext"]) == 0.3) and np.all(unhex(c["rnext"]) == 0.3)
+        modes.add(mode)
+    assert modes == {0, 1, 2, 3}
+
+
+def test_sweep_steps_against_live_reference_build(orc, tmp_path):
+    """fresh random arrays through oracle/_ref/refpart rows (skipped where it is not built)"""
+    if not orc.REFPART.exists():
+        pytest.skip("oracle/_ref/refpart not built")
+    rng = np.random.default_rng(99)
+    for mode, rows, k in ((0, 11, 22), (1, 5, 22), (2, 13, 1), (3, 13, 1)):
+        sn = 0.3 + rng.gamma(0.5, 3.0, size=(rows, k))
+        ev, u, v = rng.gamma(2.0, 0.2, size=rows), rng.gamma(1.0, 30.0, size=rows if mode == 2 else k), 6.3
+        fin, fout = tmp_path / "i.bin", tmp_path / "o.bin"
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<IIIddd", mode, rows, k, 0.3, 0.3, v))
+            f.write(sn.astype("<f8").tobytes()); f.write(ev.astype("<f8").tobytes()); f.write(u.astype("<f8").tobytes())
+        r = subprocess.run([str(orc.REFPART), "rows", str(fin), str(fout)])
+        if r.returncode == 2:
+            pytest.skip("prebuilt refpart predates the rows command")
+        raw = np.fromfile(fout, "<f8")
+        ns, nr = rows * k, (k if mode == 1 else rows * k)
+        got = orc.sweep_steps(mode, sn, ev, u, v)
+        want = (raw[:ns], raw[ns:ns + nr], raw[ns + nr:2 * ns + nr], raw[2 * ns + nr:])
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+
+
 def test_model_rate_sums_are_the_pinned_loop(orc):
     """the column sums inside the oracle's sweep (sum_rows, gpbase.hh:264-271) are, per column,
     the left-to-right loop pinned above: without -hier the theta rate after one iteration is
