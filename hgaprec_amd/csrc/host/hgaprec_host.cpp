@@ -79,6 +79,7 @@ int Env::parse(int argc, char **argv, bool echo, std::string *bad)
     else if (!strcmp(s, "-cache")) { data_cache = true; }                              // extension
     else if (!strcmp(s, "-no-tiles")) { no_tiles = true; }       // extension: hpf_config.tiling = 1 (row-major work lists only)
     else if (!strcmp(s, "-plain-rows")) { plain_rows = true; }   // extension: hpf_config.w_storage = 3 (never pack the rows of W)
+    else if (!strcmp(s, "-w48")) { w48 = true; }                 // extension, OPT-IN, lossy: hpf_config.w_storage = 2 (W in 48 bits)
     else if (i > 0) {
       if (bad) *bad = s;
       return 1;
@@ -336,13 +337,28 @@ template <typename F> void on_threads(unsigned nt, F fn)
 int Ratings::read_generic_parallel(FILE *f, HeldOut *out)
 {
   unsigned nt = std::thread::hardware_concurrency();
-  if (const char *e = getenv("HGAPREC_READ_THREADS")) nt = (unsigned)atoi(e);
+  if (const char *e = getenv("HGAPREC_READ_THREADS")) { const int v = atoi(e); nt = v < 1 ? 1u : (unsigned)v; }   // (a negative or garbage value: one thread, not 64)
   nt = std::min(nt, 64u);
   size_t min_bytes = (size_t)8 << 20;
   if (const char *e = getenv("HGAPREC_READ_PARALLEL_MIN")) min_bytes = (size_t)strtoull(e, nullptr, 0);
   struct stat st;
   if (nt < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < std::max<size_t>(min_bytes, 1)) return 1;
   const size_t size = (size_t)st.st_size;
+  {
+    // This reader holds every token as a 32-bit word (12 bytes per record, ~0.8 x the size of the text) BESIDE the
+    // records it produces (another 12 bytes each) until it returns: about twice the streaming reader's peak, 24 GB
+    // per 10^9 ratings.  Where that does not fit comfortably -- more than a quarter of the memory that is
+    // available right now, or HGAPREC_READ_PARALLEL_MAX bytes of text -- the token-by-token reader takes the file.
+    size_t max_bytes = 0;
+    if (const char *e = getenv("HGAPREC_READ_PARALLEL_MAX")) max_bytes = (size_t)strtoull(e, nullptr, 0);
+    else if (FILE *mi = fopen("/proc/meminfo", "r")) {
+      char line[128]; unsigned long long kb = 0;
+      while (fgets(line, sizeof line, mi)) if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) break;
+      fclose(mi);
+      if (kb) max_bytes = (size_t)(kb * 1024ull / 4 * 5 / 4);        // text whose tokens (0.8 x) take a quarter of it
+    }
+    if (max_bytes && size > max_bytes) return 1;
+  }
   void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
   if (map == MAP_FAILED) return 1;
   const unsigned char *d = (const unsigned char *)map;
@@ -480,7 +496,7 @@ int Ratings::read_train(const std::string &path)
   // records in file order for them (sequential reads, no shared counter): inside a row the file order,
   // whatever the number of threads.
   unsigned nt = std::thread::hardware_concurrency();
-  if (const char *e = getenv("HGAPREC_READ_THREADS")) nt = (unsigned)atoi(e);
+  if (const char *e = getenv("HGAPREC_READ_THREADS")) { const int v = atoi(e); nt = v < 1 ? 1u : (unsigned)v; }
   nt = std::max(1u, std::min(nt, 32u));
   if (nnz < ((uint64_t)1 << 22) && !getenv("HGAPREC_READ_PARALLEL_MIN")) nt = 1;
   nt = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>(nt, n));
@@ -972,23 +988,44 @@ struct BufWriter {
 // zero first -- dropping 1.1 GB of cached pages and allocating them again was half the time of a save.  The bytes of
 // the finished file are the same; while it is being written a reader sees new text followed by old instead of new
 // text followed by nothing.
+// What fopen("w") gave for free and this does not: a run killed in the middle of a save (SIGKILL, out of memory) leaves a
+// file of full length whose head is new and whose tail is old -- well-formed and wrong, where a truncated file would be
+// short and obviously so.  So a file that is being rewritten has a MARKER beside it, "<path>.writing", created before the
+// first byte and removed after the length has been set: a marker that is still there says the file next to it is not
+// whole (README "Output files").  A failed write also cuts the file at the last byte that was written.
+std::string rewrite_marker(const std::string &path) { return path + ".writing"; }
+void rewrite_begin(const std::string &path)
+{
+  const int fd = ::open(rewrite_marker(path).c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
+  if (fd >= 0) ::close(fd);                    // (a directory that takes no new file: the save itself will say so)
+}
+void rewrite_end(const std::string &path) { ::unlink(rewrite_marker(path).c_str()); }
+
 static FILE *open_rewrite(const std::string &path)
 {
+  struct stat st;
+  const bool regular = ::stat(path.c_str(), &st) != 0 || S_ISREG(st.st_mode);      // not for /dev/null or a pipe
+  if (regular) rewrite_begin(path);
   const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
   if (fd < 0) return nullptr;
   FILE *f = fdopen(fd, "w");
   if (!f) ::close(fd);
   return f;
 }
-static bool close_rewrite(FILE *f)
+static bool close_rewrite(FILE *f, const std::string &path, bool written_ok)
 {
-  bool ok = fflush(f) == 0;
+  bool ok = fflush(f) == 0 && written_ok;
   struct stat st;
-  if (ok && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode)) {      // (a pipe or /dev/null has no length to set)
-    const off_t end = ftello(f);
-    ok = end >= 0 && ftruncate(fileno(f), end) == 0;
+  const bool regular = fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode);          // (a pipe or /dev/null has no length to set)
+  if (regular) {
+    // complete: the length of the new text.  Failed: whatever reached the file, so that it is at least visibly short
+    const off_t end = ok ? ftello(f) : ::lseek(fileno(f), 0, SEEK_CUR);
+    const bool cut = end >= 0 && ftruncate(fileno(f), end) == 0;
+    ok = ok && cut;
   }
-  return (fclose(f) == 0) && ok;
+  ok = (fclose(f) == 0) && ok;
+  if (ok && regular) rewrite_end(path);         // the marker of a failed save stays
+  return ok;
 }
 
 // rows [r0, r1) of the matrix as text into out (grown when needed, never shrunk); *len = bytes
@@ -1055,7 +1092,7 @@ int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_
     if (nt == 1) put(); else writer = std::thread(put);
   }
   if (writer.joinable()) writer.join();
-  ok = close_rewrite(tf) && ok;
+  ok = close_rewrite(tf, path, ok);
   return ok ? 0 : -1;
 }
 
@@ -1076,7 +1113,7 @@ int save_vector(const std::string &path, const double *a, uint32_t rows,
     w.advance((size_t)(o - o0));
   }
   w.flush();
-  return close_rewrite(tf) ? 0 : -1;
+  return close_rewrite(tf, path, ferror(tf) == 0) ? 0 : -1;
 }
 
 // ======================================================================

@@ -32,6 +32,9 @@ struct Env {
   // GPUs (one process each) and how the per-iteration all-reduce is carried
   int device = 0; bool device_set = false;
   bool no_tiles = false;                // -no-tiles: never tile the phi passes (hpf_config.tiling = 1)
+  bool w48 = false;                     // -w48: OPT-IN, lossy -- W kept as the top 48 bits of its fp64 value (hpf_config.w_storage = 2): both phi passes ~17 % faster at
+                                        // K = 100; arithmetic and every exported number stay fp64.  Never the default: measured drift vs the exact path 1e-6 after 150 sweeps
+                                        // (contract 1e-4); tests/test_gpu_cli.py runs C1 to its stop rule both ways
   bool plain_rows = false;              // -plain-rows: W as plain doubles from the start (hpf_config.w_storage = 3; a packed handle moves there by itself when a state does not fit)
   int ngpus = 1;
   std::string comm_mode = "rccl";      // "rccl" | "host" (host-staged, for tests)
@@ -185,6 +188,11 @@ Mt19937 make_rng(double env_seed);
 size_t format_fixed8(double v, char *out);
 // row0: sequence number of the first row (a rank writing its shard of a matrix)
 // threads: how many host threads format the rows (0 = all of them)
+// a model file is rewritten in place (save_matrix / save_vector, and the part files put together by rank 0): while that
+// is going on "<path>.writing" lies beside it; a marker that outlives the run says the file is not whole
+std::string rewrite_marker(const std::string &path);
+void rewrite_begin(const std::string &path);
+void rewrite_end(const std::string &path);
 int save_matrix(const std::string &path, const double *a, uint32_t rows, uint32_t cols,
                 const uint32_t *seq2id, uint32_t nids, uint32_t row0 = 0, unsigned threads = 0);
 int save_vector(const std::string &path, const double *a, uint32_t rows,

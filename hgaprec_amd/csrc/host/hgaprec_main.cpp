@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <set>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -96,6 +97,21 @@ struct SaveBuf {
   SaveBuf(const SaveBuf &) = delete;
   SaveBuf &operator=(const SaveBuf &) = delete;
 };
+
+// part files of this rank, unlinked by an atexit hook (and, after a good run, by rank 0 behind the last barrier)
+static std::mutex g_parts_mu;
+static std::set<std::string> *g_own_parts = nullptr;
+static void unlink_own_parts() {
+  std::lock_guard<std::mutex> lk(g_parts_mu);
+  if (!g_own_parts) return;
+  for (const std::string &p : *g_own_parts) { unlink(p.c_str()); unlink(rewrite_marker(p).c_str()); }
+  g_own_parts->clear();
+}
+static void own_part(const std::string &p) {
+  std::lock_guard<std::mutex> lk(g_parts_mu);
+  if (!g_own_parts) { g_own_parts = new std::set<std::string>(); atexit(unlink_own_parts); }
+  g_own_parts->insert(p);
+}
 
 struct Driver {
   Env &env; Ratings &rt; Comm &comm; hpf_handle *h = nullptr;
@@ -207,7 +223,7 @@ struct Driver {
     cfg.hier = env.hier; cfg.bias = env.bias; cfg.binary = env.binary_data;
     cfg.novb = env.vb ? 0u : 1u;              // read by the library only where the reference reads it (vb_bias)
     cfg.tiling = env.no_tiles ? 1u : 0u;
-    cfg.w_storage = env.plain_rows ? 3u : 0u; // exact fp64 either way; 3 = never pack the rows
+    cfg.w_storage = env.w48 ? 2u : env.plain_rows ? 3u : 0u; // 0 / 3: exact fp64 either way (3 = never pack the rows); 2: -w48, opt-in, lossy
     cfg.n_users_total = n; cfg.device = env.device; cfg.n_ranks = (uint32_t)comm.world; cfg.rank = (uint32_t)comm.rank;
     cfg.s_prior = 0.3; cfg.r_prior = 0.3;
     int rc = hpf_create(&cfg, &h);
@@ -326,6 +342,7 @@ struct Driver {
   // on C2 the copy through a user-space buffer into a truncated file was 7.9 of the run's 17.6 seconds.
   // errno-style result: 0, or -1 with *bad naming the file that failed.
   static int concat_parts(const std::string &path, const std::vector<std::string> &parts, std::string *bad) {
+    rewrite_begin(path);                       // "<path>.writing" until the file is whole (hgaprec_host.cpp open_rewrite)
     const int out = ::open(path.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
     if (out < 0) { *bad = path; return -1; }
     off_t total = 0;
@@ -363,6 +380,7 @@ struct Driver {
     }
     const bool ok = ftruncate(out, total) == 0;
     if (::close(out) != 0 || !ok) { *bad = path; return -1; }
+    rewrite_end(path);
     return 0;
   }
   void finish_parts(const std::vector<std::string> &paths) {
@@ -392,7 +410,16 @@ struct Driver {
       for (int r = 0; r < comm.world; ++r) unlink(part_name(p, r).c_str());
     part_files.clear();
   }
-  std::string my_path(const std::string &path) const { return comm.world == 1 ? path : part_name(path, comm.rank); }
+  // a part file this rank has written is removed when the process exits, however it exits (die / io_die / a lost peer
+  // all go through exit()): a failed run of several ranks used to leave every part lying in the output directory --
+  // at C2 three times 1.1 GB of text per object.  While the run lasts the parts double the disk space of
+  // the user-side objects (README).
+  std::string my_path(const std::string &path) const {
+    if (comm.world == 1) return path;
+    const std::string p = part_name(path, comm.rank);
+    own_part(p);
+    return p;
+  }
 
   // GP*::save_state (gpbase.hh:389-398,743-752,971-980).  The three matrices of an object (shape, rate,
   // expectation) are fetched one after the other and written SIDE BY SIDE, a thread per file: one file's

@@ -47,6 +47,9 @@ struct Side {
   Seg *segs = nullptr; uint32_t nseg = 0;
   LongRow *longrows = nullptr; uint32_t nlong = 0;
   uint32_t nlong_wave = 0;             // the first nlong_wave of them: a wave each; the rest (a tiled side's rows with more than 64 partials) a workgroup each
+  uint32_t nzero = 0;                  // tiled side: rows WITHOUT any nonzero, kept behind the nlong entries of longrows.  Their sum is zero in every
+  bool zero_dirty = true;              // iteration: S is cleared for them once, and again only after something other than a pass wrote S (an export adds
+                                       // the prior in place, hpf_set_state, a snapshot, an all-reduce: zero_dirty) -- C2's item side has 48 000 of them
   double *partial = nullptr; uint32_t npartial = 0;
   // rows with more than HUGE_SLOTS segments are combined in two levels so that
   // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
@@ -730,7 +733,7 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
 {
   dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
   s.segs = nullptr; s.longrows = s.grouprows = s.hugerows = nullptr;
-  s.nseg = s.nlong = s.nlong_wave = s.ngroup = s.nhuge = 0;
+  s.nseg = s.nlong = s.nlong_wave = s.ngroup = s.nhuge = 0; s.nzero = 0; s.zero_dirty = true;
   dfree(s.partial); dfree(s.partial2);
   s.partial = nullptr; s.partial2 = nullptr;
   s.npartial = 0; s.npartial2 = 0;
@@ -962,16 +965,20 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     if (ngroup && (rc = dalloc(h, &partial2, (size_t)ngroup * h->ld))) break;
     // the combine gives the rows with more than COMBINE_SPLIT partials a workgroup each: they go behind the others (a stable
     // partition of the row-ordered list: a function of the matrix alone)
-    uint32_t nlong_wave = nlong;
+    // ... and the rows without any nonzero go behind both: they are not combined every iteration, only cleared when
+    // something other than a pass has written S (Side::zero_dirty)
+    uint32_t nlong_wave = nlong, nzero = 0;
     if (nlong) {
-      std::vector<LongRow> lr(nlong), big;
+      std::vector<LongRow> lr(nlong), big, none;
       HIPBRK(h, hipMemcpyAsync(lr.data(), longs, (size_t)nlong * sizeof(LongRow), hipMemcpyDeviceToHost, h->stream));
       HIPBRK(h, hipStreamSynchronize(h->stream));
       size_t w = 0;
-      for (const LongRow &x : lr) { if (x.nslots > COMBINE_SPLIT) big.push_back(x); else lr[w++] = x; }
-      if (!big.empty()) {
+      for (const LongRow &x : lr) { if (x.nslots == 0) none.push_back(x); else if (x.nslots > COMBINE_SPLIT) big.push_back(x); else lr[w++] = x; }
+      if (!big.empty() || !none.empty()) {
         std::copy(big.begin(), big.end(), lr.begin() + (ptrdiff_t)w);
+        std::copy(none.begin(), none.end(), lr.begin() + (ptrdiff_t)(w + big.size()));
         nlong_wave = (uint32_t)w;
+        nzero = (uint32_t)none.size();
         HIPBRK(h, hipMemcpyAsync(longs, lr.data(), (size_t)nlong * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
         HIPBRK(h, hipStreamSynchronize(h->stream));
       }
@@ -1067,7 +1074,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     // ---- swap the side's work list
     dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows); dfree(s.partial); dfree(s.partial2);
     s.segs = segs; s.nseg = nseg; segs = nullptr;
-    s.longrows = longs; s.nlong = nlong; s.nlong_wave = nlong_wave; longs = nullptr;
+    s.longrows = longs; s.nlong = nlong - nzero; s.nlong_wave = nlong_wave; s.nzero = nzero; s.zero_dirty = true; longs = nullptr;
     s.grouprows = groups; s.ngroup = ngroup; groups = nullptr;
     s.hugerows = huges; s.nhuge = nhuge; huges = nullptr;
     s.partial = partial; s.npartial = npartial; partial = nullptr;
@@ -1199,6 +1206,7 @@ int refresh_es(hpf_handle *h, Side &s)
                      h->cfg.r_prior, h->cfg.hier);
   int rc = check_launch(h, "materialize_es_kernel");
   if (!rc) s.es_stale = false;
+  s.zero_dirty = true;                  // the prior went into S in place: the rows without nonzeros hold it too
   return rc;
 }
 
@@ -1280,32 +1288,40 @@ bool rows_in_pieces(const hpf_handle *h) { return h->wl != WL_PLAIN; }
 int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
 {
   const int side = &own == &h->it ? 1 : 0;
+  hipStream_t st = h->stream;
   PhiArgs a;
   a.segs = own.segs; a.nseg = own.nseg; a.idx = own.pass_idx(); a.val = own.pass_val();
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
   a.chunks = own.chunks; a.ld = h->ld;
   if (a.nseg) {
     const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
-    const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, h->stream)
-                                      : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, h->stream);
+    const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, st)
+                                      : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, st);
     if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
   } else if (side == 1) {
     // the item-major pass opens an iteration (phi_pass_skips keeps the books of the fallback protocol): an empty one still does
     PhiArgs e = a; e.segs = nullptr; e.nseg = 0; e.chunks = nullptr;
-    hipLaunchKernelGGL(phi_open_kernel, dim3(1), dim3(64), 0, h->stream, e);
+    hipLaunchKernelGGL(phi_open_kernel, dim3(1), dim3(64), 0, st, e);
   }
   // the event separates the phi kernel from the combine that follows it
-  if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, h->stream));
+  if (!h->capturing) HIPCHK(h, hipEventRecord(after_kernel, st));
   auto combine = [&](const LongRow *rows, uint32_t nrows, const double *src, double *dst) {
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 16384)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(std::min<uint32_t>((nrows + 3) / 4, 16384)), dim3(256), 0, st,
                        rows, nrows, src, dst, h->ld, h->flags);
   };
   if (own.ngroup) combine(own.grouprows, own.ngroup, own.partial, own.partial2);     // level 1 of the very long rows: partial -> partial2
   if (own.nlong_wave) combine(own.longrows, own.nlong_wave, own.partial, own.S);
   if (own.nlong > own.nlong_wave)          // a tiled side's heavy rows (a partial per tile they meet): a workgroup each
     hipLaunchKernelGGL(combine_partials_wg_kernel, dim3(std::min<uint32_t>(own.nlong - own.nlong_wave, 65536)), dim3(256), (size_t)4 * h->ld * 8,
-                       h->stream, own.longrows + own.nlong_wave, own.nlong - own.nlong_wave, own.partial, own.S, h->ld, h->flags);
+                       st, own.longrows + own.nlong_wave, own.nlong - own.nlong_wave, own.partial, own.S, h->ld, h->flags);
   if (own.nhuge) combine(own.hugerows, own.nhuge, own.partial2, own.S);              // level 2: partial2 -> S
+  // rows without any nonzero: zero, like every iteration before -- written again only when S is not what the last pass left
+  // (several ranks: the item side's S is the exchange buffer, which comes back from the all-reduce holding the other ranks' sums;
+  // a caller-owned exchange buffer may have been written by its owner; a captured graph is replayed whatever happened in between)
+  if (own.nzero && (own.zero_dirty || h->capturing || (side == 1 && (h->cfg.n_ranks > 1 || h->exch_external)))) {
+    combine(own.longrows + own.nlong, own.nzero, own.partial, own.S);
+    own.zero_dirty = false;
+  }
   return check_launch(h, "phi pass");
 }
 
@@ -1931,6 +1947,7 @@ int hpf_exchange_write(hpf_handle *h, const double *host, size_t count)
   if (!h || !host || count != h->exch_count) return HPF_ERR_INVALID;
   HIPCHK(h, hipMemcpyAsync(h->exch, host, count * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->it.zero_dirty = true;
   return HPF_OK;
 }
 
@@ -2110,6 +2127,7 @@ static int set_state_impl(hpf_handle *h, hpf_state which, const double *host, si
     if ((rc = refresh_elog(h, *s))) return rc;
   }
   if ((rc = put2d(dev, (uint32_t)col0))) return rc;
+  if (kind == 0) s->zero_dirty = true;       // S was written by the caller
   if (obj <= 1) {
     if (kind == 2) s->have_E = true;
     if (kind == 3) s->have_L = true;
@@ -2365,6 +2383,7 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     s.w_from_sweep = (f & 256u) != 0;
   }
   h->derived_dirty = h->sums_dirty = hd.derived_dirty != 0;
+  h->u.zero_dirty = h->it.zero_dirty = true;
   h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
@@ -2662,10 +2681,10 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   memset(out, 0, sizeof *out);
   out->nnz = h->nnz;
   out->user_segments = h->u.nseg;
-  out->user_long_rows = h->u.nlong + h->u.nhuge;
+  out->user_long_rows = h->u.nlong + h->u.nzero + h->u.nhuge;
   out->user_huge_rows = h->u.nhuge;
   out->item_segments = h->it.nseg;
-  out->item_long_rows = h->it.nlong + h->it.nhuge;
+  out->item_long_rows = h->it.nlong + h->it.nzero + h->it.nhuge;
   out->item_huge_rows = h->it.nhuge;
   out->phi_G = (uint32_t)h->phiG; out->phi_R = (uint32_t)h->phiR; out->phi_V = (uint32_t)h->phiV;
   out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;

@@ -991,25 +991,40 @@ __global__ __launch_bounds__(256) void row_sweep_kernel(SweepArgs a)
   bool flushed = false;
 
   // software pipeline: the next row's raw sums and prior are loaded before this row is
-  // worked on (the ~90 fp64 instructions per element then cover the load latency)
+  // worked on (the ~90 fp64 instructions per element then cover the load latency).
+  // HPF_SWEEP_PIPE = 2 (tools/sweep_probe only) holds TWO rows ahead: measured in round 5, no gain (experiments.md)
+#ifndef HPF_SWEEP_PIPE
+#define HPF_SWEEP_PIPE 1
+#endif
   double snx[R]; double prn = a.r_prior;
-  if (grp < a.rows) {
+#if HPF_SWEEP_PIPE == 2
+  double sn2[R]; double pr2 = a.r_prior;
+#endif
+  auto fetch_row = [&](uint32_t r_, double (&dst)[R], double &pdst) {
+    if (r_ < a.rows) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) snx[t] = (!PIECES || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)grp * LD + g + G * t] : 0.0;
-    if (hier) prn = a.prior_E[grp];
-  }
+      for (int t = 0; t < R; ++t) dst[t] = (!PIECES || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)r_ * LD + g + G * t] : 0.0;
+      if (hier) pdst = a.prior_E[r_];
+    }
+  };
+  fetch_row(grp, snx, prn);
+#if HPF_SWEEP_PIPE == 2
+  fetch_row(grp + ngrp, sn2, pr2);
+#endif
   for (uint32_t row = grp; row < a.rows; row += ngrp) {
     const size_t base = (size_t)row * LD;
     double w[R];
 #pragma unroll
     for (int t = 0; t < R; ++t) w[t] = snx[t];
     const double pr = prn;
-    const uint32_t nr = row + ngrp;
-    if (nr < a.rows) {
+#if HPF_SWEEP_PIPE == 2
 #pragma unroll
-      for (int t = 0; t < R; ++t) snx[t] = (!PIECES || (uint32_t)(g + G * t) < LD) ? a.S[(size_t)nr * LD + g + G * t] : 0.0;
-      if (hier) prn = a.prior_E[nr];
-    }
+    for (int t = 0; t < R; ++t) snx[t] = sn2[t];
+    prn = pr2;
+    fetch_row(row + 2 * ngrp, sn2, pr2);
+#else
+    fetch_row(row + ngrp, snx, prn);
+#endif
     double wmax = 0.0, rsum = 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) {

@@ -368,10 +368,8 @@ def test_dataset_cache_runs_are_identical(tmp_path):
         assert (out / nm).read_text() == (outs[3] / nm).read_text(), nm
 
 
-def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
-    """BASELINE config C1: the MovieLens-1M stand-in (the real example/ tarball is
-    not in the reference mount): 6040 x 3681, ~1.0M ratings split 80/1/19,
-    K=20, -hier, through the TSV path, CLI vs the oracle's end-to-end run."""
+def write_c1(tmp_path):
+    """BASELINE config C1 as train / validation / test.tsv under tmp_path/ml -> (dir, n, m, K)"""
     import torch
     from hgaprec_amd import synth
     cfg = synth.CONFIGS["C1"]
@@ -391,6 +389,53 @@ def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
     for name, sel in (("train.tsv", split[order] >= 0.20), ("validation.tsv", split[order] < 0.01),
                       ("test.tsv", (split[order] >= 0.01) & (split[order] < 0.20))):
         (data / name).write_text("".join(lines[order][sel].tolist()))
+    return data, n, m, K
+
+
+def test_w48_opt_in_runs_c1_to_the_same_stop(tmp_path):
+    """`hgaprec -w48` ("opt-in perf mode with its own measured tolerance"): W kept
+    as the top 48 bits of its fp64 value (hpf_config.w_storage = 2; arithmetic, sums and every exported number stay fp64).
+    Never the default, never the headline.  C1 through the TSV path, -hier, run to the STOP RULE (hgaprec.cc:1439-1501) with
+    and without the flag: the same stop iteration, the held-out series within 1e-6, every factor file within the rule of
+    SURVEY.md 8(c), 1e-4 |b| + 5e-9 -- a convergence-length statement, where round 4 had a 150-sweep drift figure."""
+    data, n, m, K = write_c1(tmp_path)
+    args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-hier", "-rfreq", "10"]
+    outs = {}
+    for tag, extra in (("exact", []), ("w48", ["-w48"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([str(EXE)] + args + extra, cwd=d, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = d / f"n{n}-m{m}-k{K}-batch-hier-vb"
+        assert outs[tag].is_dir()
+    log48 = (outs["w48"] / "infer.log").read_text()
+    assert "48-bit (opt-in)" in log48 and "48-bit" not in (outs["exact"] / "infer.log").read_text()
+    for f in ("validation.txt", "test.txt"):
+        a, b = series(outs["w48"] / f), series(outs["exact"] / f)
+        assert [x[0] for x in a] == [x[0] for x in b], f                  # the same report steps: the same stop iteration
+        assert [x[2] for x in a] == [x[2] for x in b]
+        assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6, f
+    stop = series(outs["exact"] / "validation.txt")[-1][0]
+    assert stop >= 40                                                      # the stop rule cannot fire before (A.4)
+    ma, mb = (outs["w48"] / "max.txt").read_text().split("\t"), (outs["exact"] / "max.txt").read_text().split("\t")
+    assert ma[0] == mb[0] and ma[3] == mb[3] and abs(float(ma[2]) - float(mb[2])) <= 1e-5       # iteration, why, LL (%.5f)
+    worst = 0.0
+    for nm in ("hbeta", "htheta", "betarate", "thetarate"):
+        for suf in ("", "_shape", "_rate"):
+            ia, va = read_tsv(outs["w48"] / f"{nm}{suf}.tsv")
+            ib, vb = read_tsv(outs["exact"] / f"{nm}{suf}.tsv")
+            assert np.array_equal(ia, ib), nm + suf
+            assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf
+            worst = max(worst, float(np.max(np.abs(va - vb) / (np.abs(vb) + 1e-4))))
+    assert (outs["w48"] / "precision.txt").read_text() == (outs["exact"] / "precision.txt").read_text()
+    print(f"-w48 on C1: stop at iteration {stop} both ways; worst |a-b| / (|b| + 1e-4) over the factor files {worst:.2e}")
+
+
+def test_c1_movielens_shaped_end_to_end(orc, tmp_path):
+    """BASELINE config C1: the MovieLens-1M stand-in (the real example/ tarball is
+    not in the reference mount): 6040 x 3681, ~1.0M ratings split 80/1/19,
+    K=20, -hier, through the TSV path, CLI vs the oracle's end-to-end run."""
+    data, n, m, K = write_c1(tmp_path)
     args = ["-dir", str(data), "-n", str(n), "-m", str(m), "-k", str(K), "-hier", "-rfreq", "5", "-max-iterations", "10"]
     r = subprocess.run([str(EXE)] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]

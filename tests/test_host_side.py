@@ -383,6 +383,62 @@ def test_a_save_over_a_longer_file_leaves_no_tail(tmp_path):
         assert len((tmp_path / "v.tsv").read_text().splitlines()) == a.shape[0]
 
 
+def test_a_save_that_fails_midway_is_marked_and_cut(tmp_path):
+    """the in-place rewrite lost what fopen("w") gave -- a run that dies in the middle of a save left a
+    full-length file, new text over old.  Now "<file>.writing" lies beside a file from the first byte until its length
+    has been set: gone after a good save, still there after a failed one, and the failed file is cut at the last byte
+    written (no old tail).  The failure: a file-size limit (RLIMIT_FSIZE) that the second save runs into."""
+    import subprocess
+    import sys
+    code = r"""
+import resource, signal, sys
+import numpy as np
+sys.path.insert(0, %r)
+from hgaprec_amd import hostlib
+path = sys.argv[1]
+rng = np.random.default_rng(1)
+big = rng.gamma(0.3, 1.0, size=(3000, 20))
+assert hostlib.save_matrix(path, big, None) == 0
+import os
+assert not os.path.exists(path + ".writing")
+full = os.path.getsize(path)
+signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+resource.setrlimit(resource.RLIMIT_FSIZE, (full // 3, resource.RLIM_INFINITY))
+rc = hostlib.save_matrix(path, big * 2.0, None)
+print(rc, full, os.path.getsize(path), os.path.exists(path + ".writing"))
+""" % str(Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "m.tsv")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rc, full, now, marker = r.stdout.split()
+    assert int(rc) != 0 and marker == "True"
+    assert int(now) <= int(full) // 3                      # cut where the writing stopped: no old text behind the new
+    # the next good save clears the marker
+    assert hostlib.save_matrix(tmp_path / "m.tsv", np.ones((5, 3)), None) == 0
+    assert not (tmp_path / "m.tsv.writing").exists() and len((tmp_path / "m.tsv").read_text().splitlines()) == 5
+
+
+def test_read_threads_override_is_clamped(tmp_path, monkeypatch):
+    """HGAPREC_READ_THREADS = -3 or garbage used to become 64 threads through an unsigned cast; and text too
+    large for a quarter of the free memory (HGAPREC_READ_PARALLEL_MAX stands in) goes to the token-by-token reader --
+    the same result either way"""
+    rng = np.random.default_rng(8)
+    n, m, cnt = 300, 200, 40000
+    u, i, y = rng.integers(1, n + 1, cnt), rng.integers(1, m + 1, cnt), rng.integers(0, 6, cnt)
+    (tmp_path / "train.tsv").write_text("".join(f"{a}\t{b}\t{c}\n" for a, b, c in zip(u, i, y)))
+    monkeypatch.setenv("HGAPREC_READ_PARALLEL_MIN", "1")
+    got = []
+    for threads, pmax in (("4", None), ("-3", None), ("zebra", None), ("4", "1000")):
+        monkeypatch.setenv("HGAPREC_READ_THREADS", threads)
+        if pmax:
+            monkeypatch.setenv("HGAPREC_READ_PARALLEL_MAX", pmax)
+        R = hostlib.Ratings(n, m)
+        R.read_train(tmp_path / "train.tsv")
+        rp, c, v = R.csr()
+        got.append((rp.copy(), c.copy(), v.copy(), R.seq2user().copy(), R.seq2item().copy()))
+    for g in got[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(got[0], g))
+
+
 # ----------------------------------------------------------- stop rule -------
 def test_parallel_matrix_writer_is_byte_identical(tmp_path, monkeypatch):
     # large matrices are formatted by several threads, a wave of row blocks at a

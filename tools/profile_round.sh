@@ -40,6 +40,33 @@ if [ -x /opt/rocm/bin/hipcc ]; then
 fi
 tools/sweep_probe > $OUT/sweep_probe.json 2> $OUT/sweep_probe.log
 tools/gather_ceiling > $OUT/gather_ceiling.json 2> $OUT/gather_ceiling.log
+# 7b. the sweep at the C3-shard shape: blocks x rows held ahead; sweep_probe_pipe2 = the same source built with -DHPF_SWEEP_PIPE=2
+if [ -x /opt/rocm/bin/hipcc ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHPF_SWEEP_PIPE=2 -o tools/sweep_probe_pipe2 tools/sweep_probe.hip > /dev/null 2>&1
+fi
+: > $OUT/sweep_probe_c3shard.jsonl
+for b in 1024 2048 4096 8192; do
+  tools/sweep_probe 1250000 $b >> $OUT/sweep_probe_c3shard.jsonl 2>> $OUT/sweep_probe.log
+  [ -x tools/sweep_probe_pipe2 ] && tools/sweep_probe_pipe2 1250000 $b >> $OUT/sweep_probe_c3shard.jsonl 2>> $OUT/sweep_probe.log
+done
 # 8. report-step operations at C2 (held-out LL, ELBO, ranking evaluation)
 python tools/bench_report_step.py C2 > $OUT/report_step_c2.json 2> $OUT/report_step_c2.log
+# 9. counters for the OTHER shapes: C4 whole, and what one of 8 GPUs holds of C3 and of C5 (the first
+#    1/8 of the users of the real matrix, all items) -- the same passes as step 2, per shape, under $OUT/cfg_<label>/
+cfgprof() {
+  label=$1; shift
+  D=$OUT/cfg_$label
+  mkdir -p $D
+  L="python bench.py --lean --steps 3 --warmup 1 $*"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o k -- $L > $D/bench_lean.json 2> $D/bench_lean.log
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE" "TCC_REQ_sum TCC_TAG_STALL_sum TCC_BUSY_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"; do
+    name=$(echo $pmc | tr ' ' '_' | tr 'A-Z' 'a-z' | cut -c1-40)
+    rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $D/pmc_$name -o k -- $L > /dev/null 2> $D/pmc_$name.log
+  done
+  # the pass with its arithmetic taken out, in the same shape (roofline.gather_only_ms of the full line)
+  python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-pmc $* > $D/bench.json 2> $D/bench.log
+}
+cfgprof c4 --config C4
+cfgprof c3_shard --config C3 --user-range 0 1250000
+cfgprof c5_shard --config C5 --user-range 0 6250000
 ls -la $OUT

@@ -51,10 +51,52 @@ def main():
         (dst / "size").mkdir(exist_ok=True)
         for f in (src / "size").glob("*.json"):
             shutil.copy(f, dst / "size" / f.name)
+    traffic = {}
+    rows, merged = summary_rows(src)
+    # the other shapes (tools/profile_round.sh step 9): gpurun_out/<tag>/cfg_<label>/ -> pmc_summary_<label>.csv,
+    # kernel_stats_<label>.csv, bench_<label>.json (gather-only, tiles), bench_lean_<label>.json
+    for cd in sorted(src.glob("cfg_*")):
+        if not cd.is_dir():
+            continue
+        label = cd.name[4:]
+        crow, _ = summary_rows(cd)
+        write_rows(crow, dst / f"pmc_summary_{label}.csv")
+        for f in glob.glob(str(cd / "stats" / "**" / "*kernel_stats.csv"), recursive=True):
+            shutil.copy(f, dst / f"kernel_stats_{label}.csv")
+        for nm in ("bench.json", "bench_lean.json"):
+            if (cd / nm).exists() and (cd / nm).read_text().strip():
+                shutil.copy(cd / nm, dst / nm.replace(".json", f"_{label}.json"))
+    if rows:
+        write_rows(rows, dst / "pmc_summary.csv")
+        # the phi kernels of the DEFAULT path are the ones with the most dispatches (the bench line's
+        # w48_opt_in context block launches the f48 codec a few times as well)
+        best = {}
+        for r in rows:
+            if "hbm_side_bytes" in r and "phi_pass" in r["kernel"] and "f48" not in r["kernel"]:
+                side = "phi_item" if r["kernel"].rstrip(">").endswith("1") else "phi_user"
+                if side not in best or r["dispatches"] > best[side]["dispatches"]:
+                    best[side] = r
+        for side, r in best.items():
+            traffic[f"C2:{side}"] = r["hbm_side_bytes"]
+            traffic[f"C2:{side}:kernel"] = r["kernel"]
+    summarize_rest(tag, src, dst, merged, traffic)
+
+
+def write_rows(rows, path):
+    if not rows:
+        return
+    keys = sorted({k for r in rows for k in r}, key=lambda k: (k != "kernel", k))
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=keys)
+        w.writeheader()
+        w.writerows(rows)
+
+
+def summary_rows(src):
+    """the pmc_* passes under src -> (rows of the summary table, {kernel: {counter: (mean, dispatches, max)}})"""
     ours = ("phi_pass", "row_sweep", "combine_partials", "colsum_finalize", "radix_", "item_hist", "scan_",
             "derive_w", "repack_", "colsum_partial", "prior_update", "materialize_es")
     rows = []
-    traffic = {}
     passes = {p.name: counter_means(p) for p in src.glob("pmc_*") if p.is_dir() and not p.name.endswith("_untiled")}
     merged = defaultdict(dict)
     for cm in passes.values():
@@ -80,24 +122,15 @@ def main():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # KiB counters; FETCH_SIZE counts 64 B per 128-B request on gfx950 => x2 (MI355X_MICROARCH.md, HBM)
             row["hbm_side_bytes"] = int((2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024)
+        if "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs and cs["SQ_WAVES"][0] > 0:
+            row["valu_per_wave"] = round(cs["SQ_INSTS_VALU"][0] / cs["SQ_WAVES"][0], 1)
+        if "SQ_WAIT_INST_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"][0] > 0:
+            row["wait_inst_share"] = round(cs["SQ_WAIT_INST_ANY"][0] / cs["SQ_WAVE_CYCLES"][0], 3)       # stalled at issue
         rows.append(row)
-    if rows:
-        keys = sorted({k for r in rows for k in r}, key=lambda k: (k != "kernel", k))
-        with open(dst / "pmc_summary.csv", "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=keys)
-            w.writeheader()
-            w.writerows(rows)
-        # the phi kernels of the DEFAULT path are the ones with the most dispatches (the bench line's
-        # w48_opt_in context block launches the f48 codec a few times as well)
-        best = {}
-        for r in rows:
-            if "hbm_side_bytes" in r and "phi_pass" in r["kernel"] and "f48" not in r["kernel"]:
-                side = "phi_item" if r["kernel"].rstrip(">").endswith("1") else "phi_user"
-                if side not in best or r["dispatches"] > best[side]["dispatches"]:
-                    best[side] = r
-        for side, r in best.items():
-            traffic[f"C2:{side}"] = r["hbm_side_bytes"]
-            traffic[f"C2:{side}:kernel"] = r["kernel"]
+    return rows, merged
+
+
+def summarize_rest(tag, src, dst, merged, traffic):
     # calibration of the FETCH_SIZE x 2 correction on a kernel whose byte count is known:
     # materialize_es_kernel reads the n x ld raw sums once (its largest dispatch is the user side)
     bj = src / "bench_under_rocprof.json"

@@ -1,7 +1,7 @@
 // tools/sweep_probe.hip -- the row sweep on its own (measurement tool, not part of the library): the kernel of
 // hpf_kernels.hpp at C2's user-side shape (1M rows, K = 100, ld = 104; G = 16, R = 7) in each way of writing W --
 // plain rows, p59 built in LDS (round 3), p59 built in registers (round 4), plain doubles in pieces.  Prints ms per launch and the bytes moved.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/sweep_probe tools/sweep_probe.hip && tools/sweep_probe [rows]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DHPF_SWEEP_PIPE=2] -o tools/sweep_probe tools/sweep_probe.hip && tools/sweep_probe [rows [blocks]]
 #include "../hgaprec_amd/csrc/hpf_kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -26,12 +26,12 @@ float run(SweepArgs a, uint32_t blocks, int reps)
 int main(int argc, char **argv)
 {
   const uint32_t rows = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000000u, K = 100, ld = 104;
+  const uint32_t blocks = argc > 2 ? (uint32_t)atoi(argv[2]) : 2048u;     // the library's HPF_SWEEP_BLOCKS default
   constexpr int G = 16, R = 7;
   std::vector<double> S((size_t)rows * ld), cs(ld, 3.0e4);
   unsigned long long x = 88172645463325252ull;
   for (auto &v : S) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 40.0; }
   double *dS, *dcs, *dpart, *dprior, *drate, *dused; void *dW; uint32_t *dflags;
-  const uint32_t blocks = 2048;
   CK(hipMalloc(&dS, S.size() * 8)); CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dcs, ld * 8)); CK(hipMemcpy(dcs, cs.data(), ld * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dpart, (size_t)blocks * 112 * 8)); CK(hipMalloc(&dprior, (size_t)rows * 8)); CK(hipMalloc(&drate, (size_t)rows * 8));
@@ -45,7 +45,7 @@ int main(int argc, char **argv)
   const PackedRow pkf = {8, 14, 7, 896, 3};
   a.bias_col = -1; a.junk_col = -1; a.bias_rate_add = 0.0; a.s_prior = 0.3; a.r_prior = 0.3; a.hier = 1;
   const int reps = 20;
-  printf("{\"rows\": %u, \"ld\": %u", rows, ld);
+  printf("{\"rows\": %u, \"ld\": %u, \"blocks\": %u, \"rows_ahead\": %d", rows, ld, blocks, HPF_SWEEP_PIPE);
   {                                   // plain rows want ld = G*R = 112: same S buffer read at that stride over fewer rows
     SweepArgs p = a; p.rows = (uint32_t)((uint64_t)rows * ld / 112); p.ld = 112;
     printf(", \"plain_112_ms\": %.4f", run<G, R, SW_PLAIN>(p, blocks, reps));
