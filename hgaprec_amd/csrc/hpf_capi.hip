@@ -47,9 +47,7 @@ struct Side {
   Seg *segs = nullptr; uint32_t nseg = 0;
   LongRow *longrows = nullptr; uint32_t nlong = 0;
   uint32_t nlong_wave = 0;             // the first nlong_wave of them: a wave each; the rest (a tiled side's rows with more than 64 partials) a workgroup each
-  uint32_t nzero = 0;                  // tiled side: rows WITHOUT any nonzero, kept behind the nlong entries of longrows.  Their sum is zero in every
-  bool zero_dirty = true;              // iteration: S is cleared for them once, and again only after something other than a pass wrote S (an export adds
-                                       // the prior in place, hpf_set_state, a snapshot, an all-reduce: zero_dirty) -- C2's item side has 48 000 of them
+  bool building_tiled = false;         // build_tiled_side is cutting this side's chunks (hpf_handle::wg_of)
   double *partial = nullptr; uint32_t npartial = 0;
   // rows with more than HUGE_SLOTS segments are combined in two levels so that
   // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
@@ -131,8 +129,16 @@ struct hpf_handle {
   // 4.39 ms; 0 = in front everywhere 4.75; 2 = dealt between the tiles 4.58)
   int tile_order = 1;
   int tile_sides = 3;                   // HPF_TILE_SIDES: bit 0 the user pass, bit 1 the item pass (experiments)
-  int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 8, tile_min_run = 0; double tile_min_share = 0.15;
+  int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 0 /* 0: two segments per wave of the workgroup */, tile_min_run = 0; double tile_min_share = 0.15;
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
+  // Threads per workgroup of a packed phi pass.  0 (default): 256 -- four waves, grid-stride -- for a ROW-MAJOR side, 64 -- one
+  // wave, a chunk of two segments -- for a TILED side (round 5).  A workgroup's wave slots come back one SIMD at a time but a
+  // new workgroup needs one on each of the four SIMDs at once: with the uneven runs of a tiled list a third of the slots stood
+  // empty (SQ_WAVE_CYCLES: ~2 of 3 waves per SIMD resident on average) -- which a pass that lives on its L2 hits and on issue
+  // pays for (C4 18.65 -> 17.45 ms, a C5 shard 44.8 -> 41.5; experiments.md) and a pass bound by the fabric does not (C2's
+  // user pass, a C3 shard: unchanged).  Same segments, same order inside each: the same bits.  HPF_PHI_WG forces 64 | 128 | 256.
+  uint32_t phi_wg = 0;
+  uint32_t wg_of(const Side &s) const { return wl == WL_PLAIN ? 256u : phi_wg ? phi_wg : (s.chunks || s.building_tiled ? 64u : 256u); }   // (plain rows: phi_pass_kernel, always 256)
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
@@ -376,12 +382,16 @@ bool launch_sweep(int mode, int G, int R, const SweepArgs &a, uint32_t blocks, h
   return launch_sweep_g<SW_PLAIN>(G, R, a, blocks, st);
 }
 
+// threads per workgroup of a packed phi pass (run_phi sets it from the handle around its launch): 256 = four waves that share
+// a chunk of segments; 64 / 128 (HPF_PHI_WG, experimental) = fewer waves tied to each other's ends
+static thread_local unsigned g_phi_wg = 256;
+
 // packed W rows: G lanes per nonzero, L 16-byte pieces per lane (phi_pass_packed_kernel)
 template <template <int> class C, int G, int L>
 void launch_phipk_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
 {
-  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 1>), dim3(blocks), dim3(256), 0, st, a);
-  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 0>), dim3(blocks), dim3(256), 0, st, a);
+  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 1>), dim3(blocks), dim3(g_phi_wg), 0, st, a);
+  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 0>), dim3(blocks), dim3(g_phi_wg), 0, st, a);
 }
 template <template <int> class C, int G>
 bool launch_phipk_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
@@ -434,7 +444,7 @@ bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_
 template <int G>
 bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
 {
-#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(256), 0, st, a, sink); return true;
+#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(g_phi_wg), 0, st, a, sink); return true;
   switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) }
 #undef GO
   return false;
@@ -733,7 +743,7 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
 {
   dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows);
   s.segs = nullptr; s.longrows = s.grouprows = s.hugerows = nullptr;
-  s.nseg = s.nlong = s.nlong_wave = s.ngroup = s.nhuge = 0; s.nzero = 0; s.zero_dirty = true;
+  s.nseg = s.nlong = s.nlong_wave = s.ngroup = s.nhuge = 0;
   dfree(s.partial); dfree(s.partial2);
   s.partial = nullptr; s.partial2 = nullptr;
   s.npartial = 0; s.npartial2 = 0;
@@ -965,20 +975,19 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     if (ngroup && (rc = dalloc(h, &partial2, (size_t)ngroup * h->ld))) break;
     // the combine gives the rows with more than COMBINE_SPLIT partials a workgroup each: they go behind the others (a stable
     // partition of the row-ordered list: a function of the matrix alone)
-    // ... and the rows without any nonzero go behind both: they are not combined every iteration, only cleared when
-    // something other than a pass has written S (Side::zero_dirty)
-    uint32_t nlong_wave = nlong, nzero = 0;
+    // (the rows WITHOUT any nonzero stay in the wave kernel's part: taking them out -- cleared once, and again only after
+    // an export or a hand-over had written S -- was built in round 5 and bought nothing measurable: C2's 48 000 of them
+    // are 40 MB of zeros, ~10 us of a 45 us launch that the multi-segment light rows' chains set; experiments.md)
+    uint32_t nlong_wave = nlong;
     if (nlong) {
-      std::vector<LongRow> lr(nlong), big, none;
+      std::vector<LongRow> lr(nlong), big;
       HIPBRK(h, hipMemcpyAsync(lr.data(), longs, (size_t)nlong * sizeof(LongRow), hipMemcpyDeviceToHost, h->stream));
       HIPBRK(h, hipStreamSynchronize(h->stream));
       size_t w = 0;
-      for (const LongRow &x : lr) { if (x.nslots == 0) none.push_back(x); else if (x.nslots > COMBINE_SPLIT) big.push_back(x); else lr[w++] = x; }
-      if (!big.empty() || !none.empty()) {
+      for (const LongRow &x : lr) { if (x.nslots > COMBINE_SPLIT) big.push_back(x); else lr[w++] = x; }
+      if (!big.empty()) {
         std::copy(big.begin(), big.end(), lr.begin() + (ptrdiff_t)w);
-        std::copy(none.begin(), none.end(), lr.begin() + (ptrdiff_t)(w + big.size()));
         nlong_wave = (uint32_t)w;
-        nzero = (uint32_t)none.size();
         HIPBRK(h, hipMemcpyAsync(longs, lr.data(), (size_t)nlong * sizeof(LongRow), hipMemcpyHostToDevice, h->stream));
         HIPBRK(h, hipStreamSynchronize(h->stream));
       }
@@ -1030,7 +1039,10 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     }
     // a launch holds fewer than 2^32 work-items (the AQL packet counts them in 32 bits): at most 2^20 workgroups,
     // so a list too long for chunks of tile_chunk segments gets longer chunks
-    uint32_t CH = std::max<uint32_t>(h->tile_chunk, 1);
+    s.building_tiled = true;
+    const uint32_t wg = h->wg_of(s);
+    s.building_tiled = false;
+    uint32_t CH = h->tile_chunk ? h->tile_chunk : 2 * (wg / 64);      // two segments per wave
     // the row-major segments of a side with short rows (users: a few batches each) come in chunks of ~4096 nonzeros:
     // a workgroup that lives for two 40-nonzero rows costs more to dispatch than to run (K = 50, 10^6 light users
     // in chunks of 8: user pass 2.27 -> 2.54 ms)
@@ -1043,7 +1055,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
         cold_nnz = first_tiled.start;
       }
       const uint64_t avg = std::max<uint64_t>((uint64_t)cold_nnz / (c1 - c0), 1);
-      CHc = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096 / avg, CH), 512);
+      CHc = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096ull * wg / 256 / avg, CH), 512);
     }
     auto chunk_of = [&](const std::pair<uint32_t, uint32_t> &rg, uint32_t ch, uint32_t chc) { return (rg.first >= c0 && rg.second <= c1) ? chc : ch; };
     for (;; CH *= 2, CHc *= 2) {
@@ -1074,7 +1086,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     // ---- swap the side's work list
     dfree(s.segs); dfree(s.longrows); dfree(s.grouprows); dfree(s.hugerows); dfree(s.partial); dfree(s.partial2);
     s.segs = segs; s.nseg = nseg; segs = nullptr;
-    s.longrows = longs; s.nlong = nlong - nzero; s.nlong_wave = nlong_wave; s.nzero = nzero; s.zero_dirty = true; longs = nullptr;
+    s.longrows = longs; s.nlong = nlong; s.nlong_wave = nlong_wave; longs = nullptr;
     s.grouprows = groups; s.ngroup = ngroup; groups = nullptr;
     s.hugerows = huges; s.nhuge = nhuge; huges = nullptr;
     s.partial = partial; s.npartial = npartial; partial = nullptr;
@@ -1206,7 +1218,6 @@ int refresh_es(hpf_handle *h, Side &s)
                      h->cfg.r_prior, h->cfg.hier);
   int rc = check_launch(h, "materialize_es_kernel");
   if (!rc) s.es_stale = false;
-  s.zero_dirty = true;                  // the prior went into S in place: the rows without nonzeros hold it too
   return rc;
 }
 
@@ -1294,9 +1305,12 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
   a.chunks = own.chunks; a.ld = h->ld;
   if (a.nseg) {
-    const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+    const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own) / 64 : 4;      // waves per workgroup
+    const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
+    g_phi_wg = wpb * 64;
     const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, st)
                                       : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, st);
+    g_phi_wg = 256;
     if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
   } else if (side == 1) {
     // the item-major pass opens an iteration (phi_pass_skips keeps the books of the fallback protocol): an empty one still does
@@ -1315,13 +1329,6 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
     hipLaunchKernelGGL(combine_partials_wg_kernel, dim3(std::min<uint32_t>(own.nlong - own.nlong_wave, 65536)), dim3(256), (size_t)4 * h->ld * 8,
                        st, own.longrows + own.nlong_wave, own.nlong - own.nlong_wave, own.partial, own.S, h->ld, h->flags);
   if (own.nhuge) combine(own.hugerows, own.nhuge, own.partial2, own.S);              // level 2: partial2 -> S
-  // rows without any nonzero: zero, like every iteration before -- written again only when S is not what the last pass left
-  // (several ranks: the item side's S is the exchange buffer, which comes back from the all-reduce holding the other ranks' sums;
-  // a caller-owned exchange buffer may have been written by its owner; a captured graph is replayed whatever happened in between)
-  if (own.nzero && (own.zero_dirty || h->capturing || (side == 1 && (h->cfg.n_ranks > 1 || h->exch_external)))) {
-    combine(own.longrows + own.nlong, own.nzero, own.partial, own.S);
-    own.zero_dirty = false;
-  }
   return check_launch(h, "phi pass");
 }
 
@@ -1758,10 +1765,11 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_TILE_SIDES")) { int v = atoi(e); if (v >= 0 && v <= 3) h->tile_sides = v; }
   if (const char *e = knob("HPF_TILE_ORDER")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_order = v; }
   if (const char *e = knob("HPF_TILE_BYTES")) { long long v = atoll(e); if (v >= 1024) h->tile_bytes = (uint64_t)v; }
-  if (const char *e = knob("HPF_TILE_CHUNK")) { int v = atoi(e); if (v >= 1) h->tile_chunk = (uint32_t)v; }
+  if (const char *e = knob("HPF_TILE_CHUNK")) { int v = atoi(e); if (v >= 1) h->tile_chunk = (uint32_t)v; }       // default: two per wave of the workgroup
   if (const char *e = knob("HPF_TILE_RUN")) { int v = atoi(e); if (v >= 1) h->tile_min_run = (uint32_t)v; }
   if (const char *e = knob("HPF_TILE_SHARE")) { int v = atoi(e); if (v >= 0 && v <= 100) h->tile_min_share = v / 100.0; }
   if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
+  if (const char *e = knob("HPF_PHI_WG")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) h->phi_wg = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
   h->u.rows = n; h->it.rows = m;
@@ -1947,7 +1955,6 @@ int hpf_exchange_write(hpf_handle *h, const double *host, size_t count)
   if (!h || !host || count != h->exch_count) return HPF_ERR_INVALID;
   HIPCHK(h, hipMemcpyAsync(h->exch, host, count * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->it.zero_dirty = true;
   return HPF_OK;
 }
 
@@ -2127,7 +2134,6 @@ static int set_state_impl(hpf_handle *h, hpf_state which, const double *host, si
     if ((rc = refresh_elog(h, *s))) return rc;
   }
   if ((rc = put2d(dev, (uint32_t)col0))) return rc;
-  if (kind == 0) s->zero_dirty = true;       // S was written by the caller
   if (obj <= 1) {
     if (kind == 2) s->have_E = true;
     if (kind == 3) s->have_L = true;
@@ -2383,7 +2389,6 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     s.w_from_sweep = (f & 256u) != 0;
   }
   h->derived_dirty = h->sums_dirty = hd.derived_dirty != 0;
-  h->u.zero_dirty = h->it.zero_dirty = true;
   h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
@@ -2681,10 +2686,10 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   memset(out, 0, sizeof *out);
   out->nnz = h->nnz;
   out->user_segments = h->u.nseg;
-  out->user_long_rows = h->u.nlong + h->u.nzero + h->u.nhuge;
+  out->user_long_rows = h->u.nlong + h->u.nhuge;
   out->user_huge_rows = h->u.nhuge;
   out->item_segments = h->it.nseg;
-  out->item_long_rows = h->it.nlong + h->it.nzero + h->it.nhuge;
+  out->item_long_rows = h->it.nlong + h->it.nhuge;
   out->item_huge_rows = h->it.nhuge;
   out->phi_G = (uint32_t)h->phiG; out->phi_R = (uint32_t)h->phiR; out->phi_V = (uint32_t)h->phiV;
   out->sweep_G = (uint32_t)h->swG; out->sweep_R = (uint32_t)h->swR;
@@ -2717,7 +2722,9 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if (!a.nseg) return HPF_OK;
   uint32_t *sink = nullptr;
   if ((rc = dalloc(h, &sink, 1))) return rc;
-  const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + 3) / 4, h->phi_blocks);
+  const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own) / 64 : 4;        // the pass's own workgroups (run_phi)
+  const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
+  g_phi_wg = wpb * 64;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
@@ -2731,6 +2738,7 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / (float)reps;
   }
+  g_phi_wg = 256;
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   dfree(sink);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Profiling recipe of a round, run ON the GPU box from the repo root:
 #   bash tools/profile_round.sh r04
-# Writes under gpurun_out/<tag>/ ; tools/summarize_profiles.py turns that into profiles/<tag>/.
+# Writes under gpurun_out/<tag>/ ; tools/summarize_profiles.py turns that into profiles/<tag>/ (step 10 runs it on the
+# box and leaves the result under gpurun_out/<tag>/profiles_<tag>/: copy that into profiles/<tag>/ and commit).
 # Counters are collected in their own passes (--kernel-trace --pmc only), as the
 # MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass.
 set -u
@@ -69,4 +70,12 @@ cfgprof() {
 cfgprof c4 --config C4
 cfgprof c3_shard --config C3 --user-range 0 1250000
 cfgprof c5_shard --config C5 --user-range 0 6250000
+# 10. gpurun copies at most 64 MiB back: the summaries are made HERE (profiles/<tag>/ of this copy of the repo, then copied
+#     to $OUT/profiles_<tag>/ beside the JSON lines and the logs) and the raw rocprofv3 trees are dropped
+python tools/summarize_profiles.py $TAG > $OUT/summarize.log 2>&1
+mkdir -p $OUT/profiles_$TAG
+cp -r profiles/$TAG/. $OUT/profiles_$TAG/
+cp profiles/traffic.json profiles/c3_1gpu_reference.json $OUT/profiles_$TAG/ 2>/dev/null
+rm -rf $OUT/stats $OUT/pmc_*/ $OUT/cfg_*/stats $OUT/cfg_*/pmc_*/
+du -sh $OUT
 ls -la $OUT

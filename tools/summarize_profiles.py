@@ -54,7 +54,7 @@ def main():
     traffic = {}
     rows, merged = summary_rows(src)
     # the other shapes (tools/profile_round.sh step 9): gpurun_out/<tag>/cfg_<label>/ -> pmc_summary_<label>.csv,
-    # kernel_stats_<label>.csv, bench_<label>.json (gather-only, tiles), bench_lean_<label>.json
+    # kernel_stats_<label>.csv, bench_cfg_<label>.json (gather-only, tiles), bench_cfg_lean_<label>.json
     for cd in sorted(src.glob("cfg_*")):
         if not cd.is_dir():
             continue
@@ -65,7 +65,7 @@ def main():
             shutil.copy(f, dst / f"kernel_stats_{label}.csv")
         for nm in ("bench.json", "bench_lean.json"):
             if (cd / nm).exists() and (cd / nm).read_text().strip():
-                shutil.copy(cd / nm, dst / nm.replace(".json", f"_{label}.json"))
+                shutil.copy(cd / nm, dst / nm.replace("bench", "bench_cfg").replace(".json", f"_{label}.json"))
     if rows:
         write_rows(rows, dst / "pmc_summary.csv")
         # the phi kernels of the DEFAULT path are the ones with the most dispatches (the bench line's
