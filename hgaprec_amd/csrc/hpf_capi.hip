@@ -852,8 +852,12 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   // four tiles, user pass 3.19 ms row-major, 3.64 ms with runs of 16)
   // ... and a run is worth its fixed work from two batches on: a batch is 64 / G nonzeros (K = 50: G = 4, sixteen
   // per batch -- with runs of 16 its ten-tile user side went 2.31 -> 2.68 ms)
+  // Round 5: with one wave per workgroup on a tiled side (hpf_handle::phi_wg) a run costs less, and the bar of 16 came down
+  // to 12 where a batch holds eight nonzeros or fewer (C2 8.42 -> 8.34 ms, a C3 shard 24.3 -> 23.9; 10 is better still at C2
+  // and worse on the shard; C4 is flat from 10 to 16; K = 50's two batches of sixteen stay: 24 loses 1 %; experiments.md)
+  const uint32_t per_batch = h->phiG > 0 ? 64u / (uint32_t)h->phiG : 8u;
   const uint32_t min_run = h->tile_min_run ? h->tile_min_run                    // HPF_TILE_RUN: as given
-                                           : std::max<uint32_t>(16u, h->phiG > 0 ? 2u * (64u / (uint32_t)h->phiG) : 0u);
+                                           : (per_batch >= 16u ? 2u * per_batch : 12u);
   uint64_t light_below = (uint64_t)tiles * min_run * (tiles < 8 ? 4u : 1u);
   if (h->tile_mode == 1) light_below = 0;                         // forced: every row is regrouped
   unsigned long long *stat = nullptr;
