@@ -195,6 +195,28 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pmc_child_workload(args, cname, user_range, split):
+    """the workload arguments of the one-rank child the PMC passes profile: the same configuration and overrides as this
+    run; `user_range` = (a, b) when this rank holds a range of a larger matrix (rank 0 of a strong-scaling run: the child
+    generates exactly that range); `split`: this run drives the iteration through hpf_iterate_local_* / _global (any
+    distributed run), so the child does too"""
+    wl = ["--config", cname]
+    for k in ("n", "m", "nnz", "K"):
+        if getattr(args, k):
+            wl += [f"--{k}", str(getattr(args, k))]
+    if args.scale != 1.0:
+        wl += ["--scale", str(args.scale)]
+    if args.w48:
+        wl.append("--w48")
+    if args.w32:
+        wl.append("--w32")
+    if user_range:
+        wl += ["--user-range", str(user_range[0]), str(user_range[1])]
+    if split or args.split_iteration:
+        wl.append("--split-iteration")
+    return wl
+
+
 def kernels_sha():
     h = hashlib.sha256()
     for f in ("hpf_kernels.hpp", "hpf_build.hpp"):    # the kernels and the work lists they walk: what the traffic was measured on
@@ -814,7 +836,7 @@ def main():
                 out["w48_opt_in"] = {"error": str(ex)}
     cpu_slice = None
     cpu_note = ""
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and n_loc > 0 and nnz_loc > 0:
         # N = 1: ~4 M nonzeros of C2 (10 s of one core).  Strong scaling (C3 / C5): a contiguous 1 % USER slice of the whole
         # matrix, taken from the front of rank 0's range, capped at 10 M nonzeros (~25 s at K = 100)
         target = 4_000_000
@@ -900,10 +922,7 @@ def main():
             # N > 1 (and HPF_BENCH_FORCE_DIST): the child is ONE rank that generates exactly rank 0's user range of the
             # same matrix and runs whole iterations on it -- the item pass walks the work list rank 0 just timed; the
             # other ranks wait at the last barrier, rank 0's GPU is otherwise idle
-            wl = (["--config", cname] + [x for k in ("n", "m", "nnz", "K") if getattr(args, k) for x in (f"--{k}", str(getattr(args, k)))]
-                  + (["--scale", str(args.scale)] if args.scale != 1.0 else []) + (["--w48"] if args.w48 else []) + (["--w32"] if args.w32 else [])
-                  + (["--user-range", str(ua), str(ub)] if (strong or args.user_range) else [])
-                  + (["--split-iteration"] if (use_dist or args.split_iteration) else []))
+            wl = pmc_child_workload(args, cname, (ua, ub) if (strong or args.user_range) else None, use_dist)
             per, cal, traffic_note = pmc_passes(wl, max(n_loc, m), wi["ld"], local_rank=local_rank)
             if strong and per:
                 traffic_note += f" --user-range {ua} {ub} (rank 0's shard, one rank on rank 0's GPU)"
@@ -985,8 +1004,11 @@ def main():
             "per_kernel": per_kernel,
         }
         if cpu_slice is not None:
-            out["cpu_baseline"] = cpu_baseline(cfg, *cpu_slice, target_nnz=int(cpu_slice[0][-1]))
-            out["cpu_baseline"]["sample"] += cpu_note
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, *cpu_slice, target_nnz=int(cpu_slice[0][-1]))
+                out["cpu_baseline"]["sample"] += cpu_note
+            except Exception as ex:                       # the line must not be lost to its context block
+                out["cpu_baseline"] = {"value": None, "unit": "rating-nonzeros/s", "cores": 1, "kind": "port", "error": str(ex)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

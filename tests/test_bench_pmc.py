@@ -64,3 +64,23 @@ def test_inner_profiler_runs_do_not_inherit_an_outer_one():
     env["LD_PRELOAD"] = "/opt/rocm/lib/librocprofiler-sdk.so"
     assert "LD_PRELOAD" not in bench.clean_profiler_env(env)
     assert bench.clean_profiler_env({"A": "1"}) == {"A": "1"}
+
+
+def test_the_profiled_child_of_a_sharded_run_is_rank_0s_shard():
+    """N > 1: the child that rocprofv3 profiles is ONE rank that generates exactly rank 0's user range of
+    the same matrix and drives the iteration through the calls a rank makes; N = 1 keeps the plain workload"""
+    import argparse
+    import bench
+    base = dict(n=0, m=0, nnz=0, K=0, scale=1.0, w48=False, w32=False, split_iteration=False)
+    a = argparse.Namespace(**base)
+    assert bench.pmc_child_workload(a, "C2", None, False) == ["--config", "C2"]
+    assert bench.pmc_child_workload(a, "C3", (0, 1249876), True) == ["--config", "C3", "--user-range", "0", "1249876", "--split-iteration"]
+    a = argparse.Namespace(**dict(base, scale=0.005, K=50, w48=True))
+    assert bench.pmc_child_workload(a, "C3", (10, 20), True) == ["--config", "C3", "--K", "50", "--scale", "0.005", "--w48",
+                                                                  "--user-range", "10", "20", "--split-iteration"]
+    # HPF_BENCH_FORCE_DIST on one rank: no range, but the split calls
+    assert bench.pmc_child_workload(argparse.Namespace(**base), "C2", None, True) == ["--config", "C2", "--split-iteration"]
+    src = (ROOT / "bench.py").read_text()
+    assert 'raise SystemExit("--user-range / --split-iteration are for a single rank")' in src
+    # the child lands on the GPU of the rank that spawned it and carries none of the launcher's rendezvous variables
+    assert 'env["LOCAL_RANK"] = str(local_rank)' in src and '"MASTER_ADDR", "MASTER_PORT"' in src
