@@ -246,3 +246,40 @@ def test_fallback_from_packed_rows_cuts_the_tiled_lists_again(orc, tile_env, whe
         else:
             assert _err(w, runs[0][0][w], runs[3][0][w]) < 1e-11, w
         assert _err(w, runs[0][0][w], M.state(w)) < RTOL, w
+
+
+@pytest.mark.parametrize("K,bias", [(100, False), (200, True), (50, False)])
+def test_workgroup_size_and_chunking_do_not_change_a_bit(monkeypatch, K, bias):
+    """Round 5: a tiled side runs one wave per workgroup with chunks of two segments (hpf_handle::phi_wg; until round 4 four
+    waves shared eight segments).  Which workgroup a segment lands in decides WHEN it runs, never what it adds up: the
+    segments, the order of the nonzeros inside each and the partial slots are the same, so every state array must be
+    bit-identical between the default, round 4's launch (HPF_PHI_WG=256, HPF_TILE_CHUNK=8) and two other cuts."""
+    from hgaprec_amd.capi import Hpf
+    from tests.util import init_states
+    from oracle import orc
+    n, m = 900, 600
+    rowptr, col, val = make_problem(n, m, 40000, 31 + K, heavy_user=True, heavy_item=True, singles=True)
+    Mo = orc.Model(n, m, K, True, bias, False)
+    Mo.set_csr(rowptr, col, val)
+    Mo.initialize(3)
+    init = {w: Mo.state(w).copy() for w in init_states(True, bias)}
+    base = dict(HPF_EXPERIMENTAL="1", HPF_TILE="2", HPF_TILE_BYTES="8192", HPF_TILE_RUN="2", HPF_TILE_SHARE="1", HPF_GRAPH="0")
+    results = []
+    for extra in ({}, {"HPF_PHI_WG": "256", "HPF_TILE_CHUNK": "8"}, {"HPF_PHI_WG": "128", "HPF_TILE_CHUNK": "3"},
+                  {"HPF_PHI_WG": "64", "HPF_TILE_CHUNK": "1"}):
+        for k in ("HPF_PHI_WG", "HPF_TILE_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in {**base, **extra}.items():
+            monkeypatch.setenv(k, v)
+        D = Hpf(n, m, K, hier=True, bias=bias)
+        D.upload_csr(rowptr, col, val)
+        for w, a in init.items():
+            D.set_state(w, a)
+        wi = D.work_info()
+        assert wi["tiles_user"] > 1 and wi["tiles_item"] > 1 and wi["w_layout"] == 3, wi
+        D.iterate(4)
+        results.append({w: D.get_state(w).copy() for w in compare_states(True, bias)})
+        D.close()
+    for other in results[1:]:
+        for w in results[0]:
+            assert np.array_equal(results[0][w], other[w]), w
