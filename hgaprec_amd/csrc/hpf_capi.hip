@@ -128,6 +128,9 @@ struct hpf_handle {
   // odd ones, so that half the chip pulls over the fabric while the other half runs from its L2 (C2 item pass
   // 4.39 ms; 0 = in front everywhere 4.75; 2 = dealt between the tiles 4.58)
   int tile_order = 1;
+  uint32_t tile_split_below = 8;       // with fewer tiles than this EVERY tile is cut eight ways, a piece per XCD queue (round 4: below 32 tiles; C4's seven tiles of
+                                       // items are 2 % faster that way than levelled); from here on whole tiles are dealt eight at a time and the remainder levels
+                                       // the queues (build_tiled_side)
   int tile_sides = 3;                   // HPF_TILE_SIDES: bit 0 the user pass, bit 1 the item pass (experiments)
   int tile_mode = 2; uint64_t tile_bytes = 4u << 20; uint32_t tile_chunk = 0 /* 0: two segments per wave of the workgroup */, tile_min_run = 0; double tile_min_share = 0.15;
   uint32_t phi_blocks = 65536;      // ~one wave per few segments; the dispatcher balances
@@ -997,18 +1000,35 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
       }
     }
 
-    // ---- chunks: eight queues, one per XCD (workgroup b runs on XCD b % 8).  A tile goes to the queue
-    // with the least work so far (its segments stay together and in order); with fewer than 32 tiles
-    // every tile is cut eight ways instead.  The row-major rest (key 0) is cut eight ways, in front.
+    // ---- chunks: eight queues, one per XCD (workgroup b runs on XCD b % 8).  The first 8 * floor(t / 8) of the t tiles
+    // that hold segments go WHOLE to the queue with the least work so far (a tile's segments stay together and in order:
+    // its rows are fetched into one L2, once); the remaining t mod 8 tiles level the queues: their segments are poured, in
+    // order, into the queues up to the common fill mark, so that a levelling tile is shared by two or three XCDs instead of
+    // all eight and every queue ends at the same count (round 5; until round 4 EVERY tile was cut eight ways below 32
+    // tiles, so that each XCD fetched every tile: an eighth of C4 -- 22 tiles of users -- ran its item pass in 1.36 ms,
+    // now 1.10; 9 and 12 tiles: -4 %; from 32 tiles on nothing changes).  Below tile_split_below = 8 tiles the old rule
+    // stays (HPF_TILE_SPLIT_BELOW=N: for fewer than N tiles).  The row-major rest (key 0) is cut eight ways.
     std::vector<std::pair<uint32_t, uint32_t>> q[8], qt[8];
     uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto key_end = [&](uint32_t k) { for (uint32_t j = k + 1; j < nkeys; ++j) if (fs[j] != 0xffffffffu) return fs[j]; return nseg; };
     uint64_t tiled_segs = 0;
+    uint32_t tiles_present = 0;
+    for (uint32_t k = 1; k < nkeys; ++k) if (fs[k] != 0xffffffffu) { tiles_present++; tiled_segs += key_end(k) - fs[k]; }
+    const bool old_rule = tiles < h->tile_split_below;
+    const uint32_t whole_tiles = old_rule ? 0u : (tiles_present / 8u) * 8u;
+    uint32_t seen = 0;
+    int fill = 0;                                                  // the queue the levelling tiles are being poured into
+    const uint64_t mark = (tiled_segs + 7) / 8;                    // the common fill mark
     for (uint32_t k = 1; k < nkeys; ++k) {
       if (fs[k] == 0xffffffffu) continue;
       const uint32_t a0 = fs[k], a1 = key_end(k);
-      tiled_segs += a1 - a0;
-      if (tiles < 32) {
+      if (seen++ < whole_tiles) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+        qt[best].push_back({a0, a1}); load[best] += a1 - a0;
+        continue;
+      }
+      if (old_rule) {
         const uint64_t n = a1 - a0;
         for (int x = 0; x < 8; ++x) {
           const uint32_t lo = a0 + (uint32_t)(n * x / 8), hi = a0 + (uint32_t)(n * (x + 1) / 8);
@@ -1016,9 +1036,13 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
         }
         continue;
       }
-      int best = 0;
-      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
-      qt[best].push_back({a0, a1}); load[best] += a1 - a0;
+      for (uint32_t p0 = a0; p0 < a1;) {
+        while (fill < 7 && load[fill] >= mark) ++fill;
+        const uint64_t room = fill < 7 ? mark - load[fill] : (uint64_t)(a1 - p0);
+        const uint32_t take = (uint32_t)std::min<uint64_t>(room, a1 - p0);
+        qt[fill].push_back({p0, p0 + take}); load[fill] += take;
+        p0 += take;
+      }
     }
     // the row-major rest: an eighth per queue.  tile_order 0: in front of the tiles; 1: in front on the even
     // XCDs, behind on the odd ones (half the chip pulls over the fabric while the other half runs from L2);
@@ -1767,6 +1791,7 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_HUGE_SLOTS")) { int v = atoi(e); if (v >= 2) { h->huge_slots = (uint32_t)v; h->group_slots = std::max<uint32_t>(2, std::min<uint32_t>(64, (uint32_t)v / 2)); } }
   if (const char *e = knob("HPF_TILE")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_mode = v; }
   if (const char *e = knob("HPF_TILE_SIDES")) { int v = atoi(e); if (v >= 0 && v <= 3) h->tile_sides = v; }
+  if (const char *e = knob("HPF_TILE_SPLIT_BELOW")) { int v = atoi(e); if (v >= 0) h->tile_split_below = (uint32_t)v; }
   if (const char *e = knob("HPF_TILE_ORDER")) { int v = atoi(e); if (v >= 0 && v <= 2) h->tile_order = v; }
   if (const char *e = knob("HPF_TILE_BYTES")) { long long v = atoll(e); if (v >= 1024) h->tile_bytes = (uint64_t)v; }
   if (const char *e = knob("HPF_TILE_CHUNK")) { int v = atoi(e); if (v >= 1) h->tile_chunk = (uint32_t)v; }       // default: two per wave of the workgroup
