@@ -295,9 +295,10 @@ def sampled_rows(D, cfg, rowptr, col, val, n_users, n_items):
         return {"error": str(ex), "ok": False}
 
 
-def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2):
+def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2, tiling=0, check_rows=True):
     """one of the OTHER BASELINE shapes on this GPU, outside `value`: generate, hand over, time a few
-    iterations with the library's hipEvents, mass + sampled-row checks.  -> dict"""
+    iterations with the library's hipEvents, mass + sampled-row checks.  -> dict
+    tiling = 1: hpf_config.tiling = 1, row-major work lists only (the all-HBM item pass behind roofline.hbm_only)"""
     import torch
     from hgaprec_amd import synth
     from hgaprec_amd.capi import Hpf
@@ -315,7 +316,7 @@ def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2):
         nnz = int(rowptr[-1])
         torch.cuda.empty_cache()
         D = Hpf(n, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"], device=local_rank,
-                stream=stream.cuda_stream, n_users_total=over.get("n_users_total", n))
+                stream=stream.cuda_stream, n_users_total=over.get("n_users_total", n), tiling=tiling)
         D.upload_csr_device(rowptr, col, val)
         start_state(D, cfg, n, 0, cfg["seed"], over.get("n_users_total", n), dev)
         D.iterate(warmup)
@@ -338,8 +339,9 @@ def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2):
             "algorithmic_bytes": ab,
             "self_check": mass_check(D, cfg, nnz, val, dev),
         }
-        out["self_check"]["sampled_rows"] = sampled_rows(D, cfg, rowptr, col, val, 24, 8)
-        out["self_check"]["ok"] = bool(out["self_check"]["ok"] and out["self_check"]["sampled_rows"].get("ok"))
+        if check_rows:
+            out["self_check"]["sampled_rows"] = sampled_rows(D, cfg, rowptr, col, val, 24, 8)
+            out["self_check"]["ok"] = bool(out["self_check"]["ok"] and out["self_check"]["sampled_rows"].get("ok"))
         D.close()
         del rowptr, col, val
         torch.cuda.empty_cache()
@@ -891,6 +893,7 @@ def main():
         del rowptr, col, val
         torch.cuda.empty_cache()
 
+    hbm_only_run = None
     if rank == 0:
         # ---- the other BASELINE shapes on this GPU (outside `value`; a few seconds each)
         if world == 1 and not custom and not force_dist and not args.no_other_configs and cname == "C2":
@@ -900,6 +903,20 @@ def main():
                 out["other_configs"][label] = side_config(base, dict(over), dev, local_rank, stream)
                 log(f"[other_configs] {label}: {out['other_configs'][label].get('ms_per_step')} ms/step "
                     f"({out['other_configs'][label].get('seconds')} s)")
+            # the dominant kernel where NOTHING it gathers can be cache-resident, measured in this run (round 5; a stored
+            # figure until round 4): whole C3 on this GPU with row-major work lists (hpf_config.tiling = 1) -- its item pass
+            # gathers 10^9 rows out of an 8 GB user matrix, so its algorithmic bytes ARE its HBM bytes
+            hb = side_config("C3", {"_what": " (whole C3, row-major work lists: the all-HBM item pass)"}, dev, local_rank, stream,
+                             steps=3, warmup=1, tiling=1, check_rows=False)
+            if hb.get("kernels_ms", {}).get("phi_item_ms"):
+                hb_gbs = hb["algorithmic_bytes"]["phi_item"] / (hb["kernels_ms"]["phi_item_ms"] * 1e-3) / 1e9
+                hbm_only_run = {"GBps": hb_gbs, "phi_item_ms": hb["kernels_ms"]["phi_item_ms"], "ms_per_step": hb["ms_per_step"],
+                                "mass_ok": hb["self_check"]["ok"], "seconds": hb.get("seconds"),
+                                "what": "whole C3 (10^7 users x 10^6 items, 10^9 nonzeros, K=100) on this GPU, row-major work lists "
+                                        "(hpf_config.tiling = 1), 3 iterations: algorithmic bytes of the item pass / its hipEvent time"}
+            else:
+                hbm_only_run = {"skipped": hb.get("skipped") or hb.get("error")}
+            log(f"[hbm_only] {hbm_only_run}")
 
         # ---- roofline of the dominant kernel.  `frac` is the MEMORY-SIDE fraction: bytes that crossed from
         # the fabric into the XCDs' L2s per launch (PMC counters read in this run) / launch time / HBM peak.
@@ -971,6 +988,8 @@ def main():
                        "note": "fp64-VALU-bound (digamma + exp per element), not HBM-bound"},
         }
         hbm_only, hbm_only_note = measured_traffic("C3", "phi_item_hbm_only_GBps")
+        if hbm_only_run and hbm_only_run.get("GBps"):
+            hbm_only, hbm_only_note = hbm_only_run["GBps"], "this run: " + hbm_only_run["what"]
         out["roofline"] = {
             "bound": "hbm", "kernel": kname,
             # memory side: what crossed the fabric into the L2s per launch / launch time.  <= peak by construction
@@ -993,6 +1012,7 @@ def main():
             # the same kernel where nothing it gathers can be cache-resident (whole C3, row-major): a stored profile
             "hbm_only_frac": (hbm_only / HBM_PEAK_GBS) if hbm_only else None,
             "hbm_only_source": hbm_only_note if hbm_only else None,
+            "hbm_only_run": hbm_only_run,
             # the same pass with the arithmetic taken out: what the memory system needs for its gathers alone
             "gather_only_ms": (gather_only or {}).get(kern),
             "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
