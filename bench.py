@@ -139,13 +139,19 @@ def clean_profiler_env(env):
     return out
 
 
-def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0):
+L2_GATHER_CEILING_GBS = 31000.0   # random whole-row gathers served by the XCDs' L2s (tools/gather_ceiling.hip: 31-32 TB/s out of 3.6 MB,
+                                   # profiles/r03/gather_ceiling.json, r05 the same); the L2's own peak in the guide: 34.5 TB/s
+
+
+def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0, extra=(), steps=3):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
     slots") over `bench.py --lean --steps 3 --warmup 1` of the same workload, spawned after the
     timed region while this process is idle.  Per launch: bytes = 2 x FETCH_SIZE x 1024 / cal +
     WRITE_SIZE x 1024, the x 2 being the guide's gfx950 correction and `cal` its calibration in the
     same pass on materialize_es_kernel, which reads n_rows_big x ld doubles by construction.
+    `extra`: further counter groups, one more pass each (e.g. ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")): their per-launch
+    averages land beside FETCH_SIZE / WRITE_SIZE; a failing extra pass is noted in per["extra_error"], not fatal.
     -> ({side: {"fetch_KiB", "write_KiB", "launches"}}, cal dict, note) or (None, None, why)"""
     import csv
     import glob
@@ -166,21 +172,31 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0):
     cal = {}
     t0 = time.perf_counter()
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr.lower())
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, str(ROOT / "bench.py"), "--lean", "--steps", "3", "--warmup", "1"] + argv_workload
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=tmo)
+        for gi, group in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",)) + tuple(tuple(g) for g in extra)):
+            d = os.path.join(tmp, f"g{gi}")
+            cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, str(ROOT / "bench.py"), "--lean", "--steps", str(steps), "--warmup", "1"] + argv_workload
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=tmo)
+            except subprocess.TimeoutExpired:
+                if gi >= 2:
+                    per["extra_error"] = f"pass {' '.join(group)} timed out"
+                    continue
+                raise
             if r.returncode != 0:
-                return None, None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
-            vals, calv = parse_counter_csvs(d, ctr)
-            for sd in (0, 1):
-                v = vals[sd][1:] if len(vals[sd]) > 1 else vals[sd]        # the first launch is the warm-up iteration
-                if v:
-                    per[sd][ctr] = sum(v) / len(v)
-                    per[sd]["launches"] = len(v)
-            if calv:
-                cal[ctr] = max(calv) * 1024.0                                # the larger side's launch
+                if gi >= 2:
+                    per["extra_error"] = f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
+                    continue
+                return None, None, f"rocprofv3 --pmc {group[0]} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            for ctr in group:
+                vals, calv = parse_counter_csvs(d, ctr)
+                for sd in (0, 1):
+                    v = vals[sd][1:] if len(vals[sd]) > 1 else vals[sd]        # the first launch is the warm-up iteration
+                    if v:
+                        per[sd][ctr] = sum(v) / len(v)
+                        per[sd]["launches"] = len(v)
+                if calv and gi < 2:
+                    cal[ctr] = max(calv) * 1024.0                                # the larger side's launch
         if not all("FETCH_SIZE" in per[sd] and "WRITE_SIZE" in per[sd] for sd in (0, 1)):
             return None, None, "rocprofv3 ran but the phi kernels were not in its counter CSV"
         known_read = float(n_rows_big) * ld * 8
@@ -188,7 +204,7 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0):
              "write_over_known_write": cal["WRITE_SIZE"] / (2.0 * known_read) if cal.get("WRITE_SIZE") else None,
              "kernel": "materialize_es_kernel: reads rows x ld doubles, writes twice that, by construction",
              "seconds": round(time.perf_counter() - t0, 1)}
-        return per, c, "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over bench.py --lean --steps 3 --warmup 1"
+        return per, c, f"this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over bench.py --lean --steps {steps} --warmup 1"
     except Exception as ex:
         return None, None, f"in-run PMC passes failed: {ex}"
     finally:
@@ -335,7 +351,7 @@ def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2, tiling=0
             "value": nnz / (wall_ms * 1e-3), "ms_per_step": wall_ms,
             "ms_per_step_median_hipevent": float(np.median(its)) if its.size else None,
             "kernels_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
-            "tiles": {"user": wi["tiles_user"], "item": wi["tiles_item"]}, "w_layout": wi["w_layout"],
+            "tiles": {"user": wi["tiles_user"], "item": wi["tiles_item"]}, "w_layout": wi["w_layout"], "ld": wi["ld"],
             "algorithmic_bytes": ab,
             "self_check": mass_check(D, cfg, nnz, val, dev),
         }
@@ -350,6 +366,51 @@ def side_config(name, over, dev, local_rank, stream, steps=5, warmup=2, tiling=0
     except Exception as ex:
         torch.cuda.empty_cache()
         return {"error": str(ex), "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def side_roofline(out, wl, n_big, local_rank, budget_s):
+    """`roofline` of one of the other BASELINE shapes, from PMC passes of this run over a one-rank child that
+    runs the same shape: per pass the memory-side fraction (bytes crossing the fabric into the L2s / time / HBM peak), the L2
+    hit rate, and -- where most of the algorithmic bytes never cross the fabric -- the L2-SIDE figure: requests the L2s served x
+    128 B / time against what the machine gives random whole-row gathers out of L2.  `binding` says which ceiling the pass is
+    nearer to.  Outside `value`; `budget_s` bounds the passes (they are skipped, and say so, when it is spent)."""
+    if budget_s <= 5:
+        return {"skipped": "the time budget of the per-shape counter passes is spent"}
+    t0 = time.perf_counter()
+    per, cal, note = pmc_passes(wl, n_big, out["ld"], tmo=max(30, int(budget_s)), local_rank=local_rank,
+                                extra=(("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"),), steps=2)
+    if not per:
+        return {"skipped": note, "seconds": round(time.perf_counter() - t0, 1)}
+    fcal = cal.get("fetch_x2_over_known_read") or 1.0
+    fcal = fcal if 0.9 < fcal < 1.25 else 1.0
+    km, ab = out["kernels_ms"], out["algorithmic_bytes"]
+    blk = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic_source": note, "fetch_calibration_applied": fcal,
+           "l2_gather_ceiling_GBps": L2_GATHER_CEILING_GBS, "seconds": None, "per_kernel": {}}
+    if per.get("extra_error"):
+        blk["l2_counters"] = per["extra_error"]
+    for sd, nm in ((1, "phi_item"), (0, "phi_user")):
+        ms = km.get(nm + "_ms") or 0.0
+        if ms <= 0 or "FETCH_SIZE" not in per[sd]:
+            continue
+        traffic = int(2.0 * per[sd]["FETCH_SIZE"] * 1024.0 / fcal + per[sd]["WRITE_SIZE"] * 1024.0)
+        e = {"ms": round(ms, 4), "traffic": traffic, "achieved": traffic / (ms * 1e-3) / 1e9, "algorithmic_bytes": ab[nm],
+             "algorithmic_GBps": ab[nm] / (ms * 1e-3) / 1e9, "traffic_over_algorithmic": traffic / ab[nm]}
+        e["frac"] = e["achieved"] / HBM_PEAK_GBS
+        if "TCC_REQ_sum" in per[sd]:
+            hit, miss = per[sd].get("TCC_HIT_sum", 0.0), per[sd].get("TCC_MISS_sum", 0.0)
+            e["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
+            e["l2_side_GBps"] = per[sd]["TCC_REQ_sum"] * 128.0 / (ms * 1e-3) / 1e9
+            e["l2_side_frac"] = e["l2_side_GBps"] / L2_GATHER_CEILING_GBS
+            e["binding"] = ("l2" if e["l2_side_frac"] > e["frac"] else "hbm") if e["traffic_over_algorithmic"] < 0.5 else "hbm"
+        blk["per_kernel"][nm] = e
+    dom = max(blk["per_kernel"], key=lambda k: blk["per_kernel"][k]["ms"], default=None)
+    if dom:
+        d = blk["per_kernel"][dom]
+        blk.update({"kernel": f"{dom} pass", "achieved": d["achieved"], "frac": d["frac"], "traffic": d["traffic"], "avg_launch_ms": d["ms"],
+                    "frac_basis": "memory-side traffic (PMC counters of this run) / launch time / peak; per_kernel.*.l2_side_frac where "
+                                  "the pass lives on its L2 hits (traffic_over_algorithmic < 0.5)"})
+    blk["seconds"] = round(time.perf_counter() - t0, 1)
+    return blk
 
 
 # what 8 GPUs hold of C3 and C5 (the size of one nnz-balanced shard, all items), and C4 whole: every
@@ -393,6 +454,10 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for the "
                          "single-GPU smoke test of the N>1 code path)")
+    ap.add_argument("--comm", choices=("torch", "library"), default="torch",
+                    help="N > 1: who runs the exchange.  torch = torch.distributed.all_reduce on the bound exchange tensor (default, "
+                         "what the SCALE runs time); library = hpf_comm_init + hpf_iterate: the library's own dlopen'ed RCCL calls on "
+                         "its own communication stream -- the path `hgaprec -ngpus N -comm rccl` ships (needs one GPU per rank)")
     ap.add_argument("--single-allreduce", action="store_true",
                     help="N > 1: ONE all-reduce of [m x ld | ld] after the user half instead of the overlapped pair")
     ap.add_argument("--no-1gpu-reference", action="store_true",
@@ -545,8 +610,15 @@ def main():
     log(f"[rank {rank}] generated users [{ua}, {ub}) x {m} items, nnz={nnz_loc} in {t_gen:.1f}s")
     torch.cuda.empty_cache()             # the generator's temporaries go back to the driver: the library allocates with hipMalloc
 
+    lib_comm = use_dist and args.comm == "library"
+    if lib_comm and args.same_device and world > 1:
+        raise SystemExit("--comm library: RCCL wants one GPU per rank (--same-device is for --backend gloo --comm torch)")
+    # one rank taking the distributed path: n_ranks = 2 so that the handle runs the pieces a rank of several runs -- except with the
+    # library's communicator, whose size is the handle's n_ranks: a real ONE-rank communicator then (hpf_iterate goes through the
+    # library's collectives whenever a communicator is there)
     D = Hpf(n_loc, m, K, hier=cfg["hier"], bias=cfg["bias"], binary=cfg["binary"],
-            device=local_rank, stream=stream.cuda_stream, n_ranks=2 if ((force_dist or args.split_iteration) and world == 1) else world,
+            device=local_rank, stream=stream.cuda_stream,
+            n_ranks=2 if ((force_dist or args.split_iteration) and world == 1 and not lib_comm) else world,
             rank=rank, n_users_total=n_total, w_storage=1 if args.w32 else 2 if args.w48 else 0)
     xbuf = None
     if use_dist:
@@ -565,13 +637,30 @@ def main():
     t_state = time.perf_counter() - t0
     log(f"[rank {rank}] device hand-over: csr {t_upload:.2f}s, state {t_state:.2f}s")
 
-    def step():
+    if lib_comm:
+        # the 128-byte RCCL id from rank 0 over the process group (any backend), then the collective hpf_comm_init
+        box = [Hpf.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        D.comm_init(bytes(box[0]))
+
+    def step(single=args.single_allreduce):
         if args.split_iteration and not use_dist:
             D.iterate_local_items()
             D.iterate_local_users()
             D.iterate_global()
         elif not use_dist:
             D.iterate(1)
+        elif lib_comm:
+            # what `hgaprec -ngpus N -comm rccl [-single-allreduce]` runs (hgaprec_main.cpp Driver::iterate): hpf_iterate = item pass,
+            # hpf_allreduce_items_begin on the library's communication stream, user half, hpf_allreduce_exchange (the tail + the
+            # wait for both), item sweep; or the pieces around ONE hpf_allreduce_exchange on the kernels' stream
+            if single:
+                D.iterate_local_items()
+                D.iterate_local_users()
+                D.allreduce_exchange()
+                D.iterate_global()
+            else:
+                D.iterate(1)
         else:
             # the item shape sums (m*ld doubles) are final after the item-major phi
             # pass, which runs first: their all-reduce runs on RCCL's stream while
@@ -579,7 +668,7 @@ def main():
             # (ld doubles) follows in a second, tiny one.  The item update then
             # consumes the NEW theta sums, like hgaprec.cc:1380-1386.
             D.iterate_local_items()
-            if args.single_allreduce:
+            if single:
                 D.iterate_local_users()
                 dist.all_reduce(xbuf)
             else:
@@ -621,6 +710,25 @@ def main():
                     for r, v in enumerate(allr)]
     else:
         nnz_total = nnz_loc
+
+    modes_ms = None
+    if use_dist:
+        # both exchange orders in the same run, outside `value` (the first hardware run decides the default with data): a few more
+        # iterations each way, max over ranks of the wall time per iteration, and what the stream had to wait for
+        modes_ms = {}
+        k2 = max(2, min(args.steps, 5))
+        for nm, sg in (("pair_overlapped", False), ("single_fused", True)):
+            step(sg)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step(sg)
+            fence()
+            tt = torch.tensor([(time.perf_counter() - t1) / k2 * 1e3, D.mean_timing(k2)["exchange_wait_ms"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            modes_ms[nm] = {"ms_per_step": round(float(tt[0]), 4), "exposed_allreduce_ms_max": round(float(tt[1]), 4)}
+        modes_ms["timed_region_used"] = "single_fused" if args.single_allreduce else "pair_overlapped"
+        modes_ms["iterations_each"] = k2
 
     replica_check = None
     if use_dist:
@@ -664,7 +772,10 @@ def main():
                 # ring bus bandwidth, 2 (N-1)/N x bytes / time (the per-link figure xGMI is judged by)
                 "bus_GBps": round(2 * (world - 1) / max(world, 1) * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
                 "mode": "one fused all-reduce after the user half" if args.single_allreduce
-                        else "item sums all-reduced underneath the user half + a tail of ld doubles"}
+                        else "item sums all-reduced underneath the user half + a tail of ld doubles",
+                # who issued the collectives of the TIMED region: torch.distributed on torch's stream, or the library's own
+                # dlopen'ed RCCL calls on its communication stream (hpf_comm_init + hpf_iterate: what hgaprec -comm rccl runs)
+                "path": "library" if lib_comm else "torch"}
         if rccl_log and rank == 0:
             try:
                 txt = Path(rccl_log).read_text(errors="replace").splitlines()
@@ -776,7 +887,7 @@ def main():
             # `value` is computed from (this rank's handle; N > 1: rank 0's)
             "ms_per_step_median_hipevent": float(np.median(it_ms)) if it_ms.size else None,
             "ms_per_step_hipevent_min_max": [float(it_ms.min()), float(it_ms.max())] if it_ms.size else None,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else ("weak" if world > 1 else "none"), "vs_baseline": None,
             "dtype": "f64 arithmetic, W stored f32 (opt-in mode)" if args.w32 else
                      "f64 arithmetic, W stored in 48 bits (opt-in mode)" if args.w48 else "f64", "data": "synthetic",
             "config": {
@@ -806,6 +917,7 @@ def main():
             out["exposed_allreduce_ms"] = {"max": max(r["exchange_wait_ms"] for r in per_rank),
                                            "mean": sum(r["exchange_wait_ms"] for r in per_rank) / world}
             out["compute_ms"] = {"max": max(comp), "min": min(comp)}
+            out["allreduce_modes_ms"] = modes_ms
         if rccl is not None:
             out["rccl"] = rccl
         if (world == 1 and not custom and not force_dist and not args.lean
@@ -899,10 +1011,18 @@ def main():
         if world == 1 and not custom and not force_dist and not args.no_other_configs and cname == "C2":
             out["other_configs"] = {"note": "outside `value`: other BASELINE shapes timed in this same run on this GPU "
                                             "(5 iterations after 2 warm-up; wall clock and the library's hipEvents)"}
+            pmc_budget = 0.0 if args.no_pmc else float(os.environ.get("HPF_BENCH_SIDE_PMC_SECONDS", "150"))
             for label, base, over in OTHER_CONFIGS:
-                out["other_configs"][label] = side_config(base, dict(over), dev, local_rank, stream)
-                log(f"[other_configs] {label}: {out['other_configs'][label].get('ms_per_step')} ms/step "
-                    f"({out['other_configs'][label].get('seconds')} s)")
+                oc = side_config(base, dict(over), dev, local_rank, stream)
+                out["other_configs"][label] = oc
+                log(f"[other_configs] {label}: {oc.get('ms_per_step')} ms/step ({oc.get('seconds')} s)")
+                if oc.get("kernels_ms") and not args.no_pmc:
+                    # the same shape in a one-rank child under the counters (sizes as overrides of the base config)
+                    wl = ["--config", base] + [x for k in ("n", "nnz") if k in over for x in (f"--{k}", str(over[k]))]
+                    c2 = dict(synth.CONFIGS[base]); c2.update(over)
+                    oc["roofline"] = side_roofline(oc, wl, max(c2["n"], c2["m"]), local_rank, pmc_budget)
+                    pmc_budget -= oc["roofline"].get("seconds") or 0.0
+                    log(f"[other_configs] {label} roofline: {json.dumps(oc['roofline'].get('per_kernel', oc['roofline']))[:400]}")
             # the dominant kernel where NOTHING it gathers can be cache-resident, measured in this run (round 5; a stored
             # figure until round 4): whole C3 on this GPU with row-major work lists (hpf_config.tiling = 1) -- its item pass
             # gathers 10^9 rows out of an 8 GB user matrix, so its algorithmic bytes ARE its HBM bytes

@@ -40,6 +40,7 @@ EXPORTS = [
     "hpf_snapshot_size", "hpf_snapshot_save", "hpf_snapshot_load",
     "hpf_get_work_info", "hpf_upload_csr_device", "hpf_get_csc", "hpf_set_state_device", "hpf_get_state_device",
     "hpf_iteration_times", "hpf_debug_poke_index", "hpf_start_sums", "hpf_host_alloc", "hpf_host_free",
+    "hpf_heldout_bind", "hpf_heldout_ll_bound",
 ]
 
 
@@ -101,7 +102,8 @@ class HpfWorkInfo(C.Structure):
         ("tile_rows_user", C.c_uint32), ("tile_rows_item", C.c_uint32),
         ("heavy_min_nnz_user", C.c_uint64), ("heavy_min_nnz_item", C.c_uint64),
         ("w_fallbacks", C.c_uint32), ("notes", C.c_uint32),
-        ("start_sums_pending", C.c_uint32), ("reserved0", C.c_uint32),
+        ("start_sums_pending", C.c_uint32), ("tile_chunk_user", C.c_uint32), ("tile_chunk_item", C.c_uint32),
+        ("phi_build", C.c_uint32),
     ]
 
 
@@ -118,6 +120,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = Path(path) if path else LIB_PATH
+    # A/B measurements only (tools/, profiles/): HPF_EXPERIMENTAL=1 HPF_LIB=<file name or path> loads another build of the
+    # library -- e.g. last round's, kept beside this one -- in place of libhpf_hip.so
+    if path is None and os.environ.get("HPF_EXPERIMENTAL") == "1" and os.environ.get("HPF_LIB"):
+        alt = Path(os.environ["HPF_LIB"])
+        p = alt if alt.is_absolute() else _PKG / alt
     # One HIP runtime per process.  libhpf_hip.so is linked against the system ROCm
     # (libamdhip64.so.7); a torch wheel brings its own copy of the HIP and HSA runtimes.
     # If the system copy is mapped first and torch is imported later, the process ends up
@@ -165,6 +172,9 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     lib.hpf_bind_exchange_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.hpf_heldout_ll.argtypes = [vp, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t, dp,
                                    C.POINTER(C.c_uint64)]
+    if hasattr(lib, "hpf_heldout_bind"):          # (an older build loaded through HPF_LIB for an A/B run lacks the v8 calls)
+        lib.hpf_heldout_bind.argtypes = [vp, C.c_int, u32p, u32p, C.POINTER(C.c_int32), C.c_size_t]
+        lib.hpf_heldout_ll_bound.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_uint64)]
     lib.hpf_elbo.argtypes = [vp, dp]
     u64p = C.POINTER(C.c_uint64)
     lib.hpf_scores.argtypes = [vp, u32p, C.c_uint32, dp]
@@ -448,6 +458,21 @@ class Hpf:
         s, c = C.c_double(), C.c_uint64()
         self._check(self.lib.hpf_heldout_ll(self._h, _ptr(u, C.c_uint32), _ptr(i, C.c_uint32),
                                             _ptr(y, C.c_int32), u.size, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def heldout_bind(self, slot, u, i, y) -> None:
+        """validate and upload a held-out set once (hpf_heldout_bind); heldout_ll_bound(slot) then evaluates it"""
+        u = np.ascontiguousarray(u, dtype=np.uint32)
+        i = np.ascontiguousarray(i, dtype=np.uint32)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        if not (u.size == i.size == y.size):
+            raise ValueError("u, i, y differ in length")
+        self._check(self.lib.hpf_heldout_bind(self._h, int(slot), _ptr(u, C.c_uint32), _ptr(i, C.c_uint32),
+                                              _ptr(y, C.c_int32), u.size))
+
+    def heldout_ll_bound(self, slot):
+        s, c = C.c_double(), C.c_uint64()
+        self._check(self.lib.hpf_heldout_ll_bound(self._h, int(slot), C.byref(s), C.byref(c)))
         return s.value, c.value
 
     def elbo(self) -> float:

@@ -1003,13 +1003,16 @@ void rewrite_end(const std::string &path) { ::unlink(rewrite_marker(path).c_str(
 
 static FILE *open_rewrite(const std::string &path)
 {
-  struct stat st;
-  const bool regular = ::stat(path.c_str(), &st) != 0 || S_ISREG(st.st_mode);      // not for /dev/null or a pipe
-  if (regular) rewrite_begin(path);
+  // the marker follows the open of the file itself: a target that cannot be opened (EACCES, no room for a new
+  // inode) is an old file nobody touched, and a marker beside it would call it broken.  Nothing has been written yet when
+  // the marker appears, so it still precedes the first byte.
   const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
   if (fd < 0) return nullptr;
+  struct stat st;
+  const bool regular = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);               // not for /dev/null or a pipe
+  if (regular) rewrite_begin(path);
   FILE *f = fdopen(fd, "w");
-  if (!f) ::close(fd);
+  if (!f) { ::close(fd); if (regular) rewrite_end(path); }
   return f;
 }
 static bool close_rewrite(FILE *f, const std::string &path, bool written_ok)

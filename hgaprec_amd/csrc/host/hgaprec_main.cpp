@@ -342,9 +342,13 @@ struct Driver {
   // on C2 the copy through a user-space buffer into a truncated file was 7.9 of the run's 17.6 seconds.
   // errno-style result: 0, or -1 with *bad naming the file that failed.
   static int concat_parts(const std::string &path, const std::vector<std::string> &parts, std::string *bad) {
-    rewrite_begin(path);                       // "<path>.writing" until the file is whole (hgaprec_host.cpp open_rewrite)
     const int out = ::open(path.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
     if (out < 0) { *bad = path; return -1; }
+    // "<path>.writing" until the file is whole (hgaprec_host.cpp open_rewrite) -- after the open has succeeded (a target
+    // that cannot be opened is an old file nobody touched) and only beside a regular file
+    struct stat ost;
+    const bool regular = fstat(out, &ost) == 0 && S_ISREG(ost.st_mode);
+    if (regular) rewrite_begin(path);
     off_t total = 0;
     bool in_kernel = true;
     std::vector<char> buf;
@@ -378,9 +382,9 @@ struct Driver {
       }
       ::close(in);
     }
-    const bool ok = ftruncate(out, total) == 0;
+    const bool ok = !regular || ftruncate(out, total) == 0;
     if (::close(out) != 0 || !ok) { *bad = path; return -1; }
-    rewrite_end(path);
+    if (regular) rewrite_end(path);
     return 0;
   }
   void finish_parts(const std::vector<std::string> &paths) {
@@ -662,12 +666,20 @@ struct Driver {
     }
   }
 
+  bool held_bound[2] = {false, false};
   // HGAPRec::compute_likelihood (hgaprec.cc:1439-1501); returns true to stop
   bool compute_likelihood(bool validation) {
     const HeldOut &ho = validation ? lvalid : ltest;
     double s = 0.0; uint64_t cnt = 0;
-    int rc = hpf_heldout_ll(h, ho.u.data(), ho.i.data(), ho.y.data(), ho.u.size(), &s, &cnt);
-    if (rc) die("hpf_heldout_ll", rc);
+    // the same pairs at every report step: validated and uploaded once (ABI v8), then kernel + ordered sum only
+    const int slot = validation ? 0 : 1;
+    if (!held_bound[slot]) {
+      int rc0 = hpf_heldout_bind(h, slot, ho.u.data(), ho.i.data(), ho.y.data(), ho.u.size());
+      if (rc0) die("hpf_heldout_bind", rc0);
+      held_bound[slot] = true;
+    }
+    int rc = hpf_heldout_ll_bound(h, slot, &s, &cnt);
+    if (rc) die("hpf_heldout_ll_bound", rc);
     double acc[2] = {s, (double)cnt};
     comm_check(comm.allreduce_sum(acc, 2), "likelihood all-reduce");
     const uint32_t kk = (uint32_t)acc[1];

@@ -47,7 +47,6 @@ struct Side {
   Seg *segs = nullptr; uint32_t nseg = 0;
   LongRow *longrows = nullptr; uint32_t nlong = 0;
   uint32_t nlong_wave = 0;             // the first nlong_wave of them: a wave each; the rest (a tiled side's rows with more than 64 partials) a workgroup each
-  bool building_tiled = false;         // build_tiled_side is cutting this side's chunks (hpf_handle::wg_of)
   double *partial = nullptr; uint32_t npartial = 0;
   // rows with more than HUGE_SLOTS segments are combined in two levels so that
   // no wave walks a chain of thousands of partials: groups of GROUP_SLOTS
@@ -61,7 +60,7 @@ struct Side {
   // index p_idx / p_val, and workgroup b takes the segments chunks[b]
   uint32_t *p_idx = nullptr; uint8_t *p_val = nullptr;
   uint2 *chunks = nullptr; uint32_t nchunk_blocks = 0;
-  uint32_t tiles = 0, tile_rows = 0; uint64_t tiled_nnz = 0, light_below = 0;
+  uint32_t tiles = 0, tile_rows = 0, chunk_segs = 0; uint64_t tiled_nnz = 0, light_below = 0;
   const uint32_t *pass_idx() const { return p_idx ? p_idx : idx; }
   const uint8_t *pass_val() const { return p_idx ? p_val : val; }
   int32_t bias_col = -1, junk_col = -1;
@@ -100,6 +99,9 @@ struct hpf_handle {
   bool jacobi = false;
   double *u_colsum_prev = nullptr;      // [ld]
   bool start_sums_done = false;         // jacobi on several ranks: the start state's sum_u E[theta] has been handed to the exchange
+  bool tail_partial = false;            // hpf_start_sums left THIS RANK'S PART of that sum in the tail for a caller that owns the exchange;
+                                        // hpf_work_info.start_sums_pending keeps reading 1 until the first pass of the next iteration, so that a
+                                        // caller may look at it before or after hpf_start_sums
   double *logfact = nullptr;
   int64_t *rowptr_dev = nullptr;   // user CSR row pointers (ranking mask, CSC build)
   int64_t *colptr_dev = nullptr;   // item-major (CSC) column pointers, built on device
@@ -141,7 +143,11 @@ struct hpf_handle {
   // pays for (C4 18.65 -> 17.45 ms, a C5 shard 44.8 -> 41.5; experiments.md) and a pass bound by the fabric does not (C2's
   // user pass, a C3 shard: unchanged).  Same segments, same order inside each: the same bits.  HPF_PHI_WG forces 64 | 128 | 256.
   uint32_t phi_wg = 0;
-  uint32_t wg_of(const Side &s) const { return wl == WL_PLAIN ? 256u : phi_wg ? phi_wg : (s.chunks || s.building_tiled ? 64u : 256u); }   // (plain rows: phi_pass_kernel, always 256)
+  uint32_t wg_of(bool tiled) const { return wl == WL_PLAIN ? 256u : phi_wg ? phi_wg : (tiled ? 64u : 256u); }   // (plain rows: phi_pass_kernel, always 256)
+  // build of the packed pass kernels (round 6; the p59 shapes of six pieces per lane): waves per SIMD the registers are held
+  // to, the owner's factors in LDS, rows read by half their lanes.  HPF_PHI_WAVES / HPF_PHI_OWN_LDS / HPF_PHI_X2 force them.
+  int phi_waves = 3, phi_own_lds = 0, phi_x2 = 0; uint32_t phi_lds_pad = 0;
+  uint32_t nz_per_batch() const { return phiG > 0 ? 64u / (uint32_t)(phi_x2 && wl == WL_P59 && phiG >= 8 && phiR == 6 ? phiG / 2 : phiG) : 8u; }
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
@@ -158,9 +164,17 @@ struct hpf_handle {
   int graph_mode = -1;                  // -1 auto, 0 off, 1 on
   uint64_t graph_nnz_max = 4u << 20;
   hipGraphExec_t graph_exec = nullptr;
+  // the same for a rank of several (round 6): the iteration is cut by its two collectives, so it is THREE graphs -- the item
+  // pass | the user pass + the user sweep | the item sweep -- replayed by hpf_iterate_local_items, hpf_iterate_local_users and
+  // hpf_iterate_global (and so by hpf_iterate with a communicator) around whatever exchange the caller or the library runs
+  hipGraphExec_t split_exec[3] = {nullptr, nullptr, nullptr};
   bool capturing = false;               // inside stream capture: no events, no counters
-  int phase = 0;                        // 0 idle | 1 items pass done | 2 users pass done | 3 user sweep done
+  int phase = 0;                        // 0 idle | 1 items pass done | 2 users pass done | 3 user sweep done; as graph replays: 4 item piece done | 5 user piece done
   bool ring_graphed[RING] = {};         // slot was a graph replay: only events 0 and 6 exist
+  // held-out sets bound once (hpf_heldout_bind): indices and ratings on the device, the per-pair values in a kept
+  // page-locked buffer the DMA writes directly
+  struct HeldSet { uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr, *hout = nullptr; size_t cnt = 0; bool bound = false; };
+  HeldSet held[HPF_HELDOUT_SLOTS];
   std::string err;
 };
 
@@ -255,6 +269,13 @@ int dalloc(hpf_handle *h, T **p, size_t n)
 }
 
 void dfree(void *p) { if (p) (void)hipFree(p); }
+
+void free_held(hpf_handle::HeldSet &hs)
+{
+  dfree(hs.du); dfree(hs.di); dfree(hs.dy); dfree(hs.dout);
+  if (hs.hout) (void)hipHostFree(hs.hout);
+  hs = hpf_handle::HeldSet();
+}
 
 void free_side(Side &s, bool S_external)
 {
@@ -385,81 +406,107 @@ bool launch_sweep(int mode, int G, int R, const SweepArgs &a, uint32_t blocks, h
   return launch_sweep_g<SW_PLAIN>(G, R, a, blocks, st);
 }
 
-// threads per workgroup of a packed phi pass (run_phi sets it from the handle around its launch): 256 = four waves that share
-// a chunk of segments; 64 / 128 (HPF_PHI_WG, experimental) = fewer waves tied to each other's ends
-static thread_local unsigned g_phi_wg = 256;
+// how a packed phi pass is launched: workgroups x threads (256 = four waves that share a chunk of segments, 64 = one wave: a
+// tiled side), and the build of the kernel -- waves per SIMD its registers are held to, the owner's factors in registers or
+// in LDS, rows read by all their lanes or by half of them (codec_p59x2)
+struct PhiLaunch { uint32_t blocks, wg; hipStream_t st; int waves, own_lds, x2; uint32_t lds_pad; };    // lds_pad: dynamic LDS bytes per wave, asked for
+                                                                                                         // and never touched -- caps the waves a CU holds (HPF_PHI_LDS_PAD: occupancy experiments)
+
+template <template <int> class C> struct is_p59 { static constexpr bool value = false; };
+template <> struct is_p59<codec_p59> { static constexpr bool value = true; };
 
 // packed W rows: G lanes per nonzero, L 16-byte pieces per lane (phi_pass_packed_kernel)
-template <template <int> class C, int G, int L>
-void launch_phipk_t(int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+template <template <int> class C, int G, int L, int WAVES, int OWN>
+void launch_phipk_v(int side, const PhiArgs &a, const PhiLaunch &pl)
 {
-  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 1>), dim3(blocks), dim3(g_phi_wg), 0, st, a);
-  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 0>), dim3(blocks), dim3(g_phi_wg), 0, st, a);
+  const size_t dyn = (size_t)pl.lds_pad * (pl.wg / 64);
+  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, WAVES, OWN, 1>), dim3(pl.blocks), dim3(pl.wg), dyn, pl.st, a);
+  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, WAVES, OWN, 0>), dim3(pl.blocks), dim3(pl.wg), dyn, pl.st, a);
+}
+template <template <int> class C, int G, int L>
+void launch_phipk_t(int side, const PhiArgs &a, const PhiLaunch &pl)
+{
+  // the other builds exist for the shapes of six pieces per lane -- K = 50, 100, 200: (4, 6), (8, 6), (16, 6) -- of the lossless rows
+  if constexpr (is_p59<C>::value && L == 6) {
+    if (pl.x2) {
+      if constexpr (G >= 8) {
+        if (pl.own_lds) launch_phipk_v<codec_p59x2, G / 2, 12, 2, 1>(side, a, pl);
+        else            launch_phipk_v<codec_p59x2, G / 2, 12, 2, 0>(side, a, pl);
+        return;
+      }
+    }
+    if (pl.waves == 4 && pl.own_lds) { launch_phipk_v<C, G, L, 4, 1>(side, a, pl); return; }
+    if (pl.waves == 4) { launch_phipk_v<C, G, L, 4, 0>(side, a, pl); return; }
+    if (pl.own_lds) { launch_phipk_v<C, G, L, 3, 1>(side, a, pl); return; }
+  }
+  launch_phipk_v<C, G, L, 3, 0>(side, a, pl);
 }
 template <template <int> class C, int G>
-bool launch_phipk_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phipk_l(int L, int side, const PhiArgs &a, const PhiLaunch &pl)
 {
   switch (L) {
-    case 1: launch_phipk_t<C, G, 1>(side, a, blocks, st); return true;
-    case 2: launch_phipk_t<C, G, 2>(side, a, blocks, st); return true;
-    case 3: launch_phipk_t<C, G, 3>(side, a, blocks, st); return true;
-    case 4: launch_phipk_t<C, G, 4>(side, a, blocks, st); return true;
-    case 5: launch_phipk_t<C, G, 5>(side, a, blocks, st); return true;
-    case 6: launch_phipk_t<C, G, 6>(side, a, blocks, st); return true;
-    case 7: launch_phipk_t<C, G, 7>(side, a, blocks, st); return true;
-    case 8: launch_phipk_t<C, G, 8>(side, a, blocks, st); return true;
+    case 1: launch_phipk_t<C, G, 1>(side, a, pl); return true;
+    case 2: launch_phipk_t<C, G, 2>(side, a, pl); return true;
+    case 3: launch_phipk_t<C, G, 3>(side, a, pl); return true;
+    case 4: launch_phipk_t<C, G, 4>(side, a, pl); return true;
+    case 5: launch_phipk_t<C, G, 5>(side, a, pl); return true;
+    case 6: launch_phipk_t<C, G, 6>(side, a, pl); return true;
+    case 7: launch_phipk_t<C, G, 7>(side, a, pl); return true;
+    case 8: launch_phipk_t<C, G, 8>(side, a, pl); return true;
   }
   return false;
 }
 template <template <int> class C>
-bool launch_phipk_g(int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phipk_g(int G, int L, int side, const PhiArgs &a, const PhiLaunch &pl)
 {
   switch (G) {
-    case 4:  return launch_phipk_l<C, 4>(L, side, a, blocks, st);
-    case 8:  return launch_phipk_l<C, 8>(L, side, a, blocks, st);
-    case 16: return launch_phipk_l<C, 16>(L, side, a, blocks, st);
-    case 32: return launch_phipk_l<C, 32>(L, side, a, blocks, st);
-    case 64: return launch_phipk_l<C, 64>(L, side, a, blocks, st);
+    case 4:  return launch_phipk_l<C, 4>(L, side, a, pl);
+    case 8:  return launch_phipk_l<C, 8>(L, side, a, pl);
+    case 16: return launch_phipk_l<C, 16>(L, side, a, pl);
+    case 32: return launch_phipk_l<C, 32>(L, side, a, pl);
+    case 64: return launch_phipk_l<C, 64>(L, side, a, pl);
   }
   return false;
 }
 template <int G>
-bool launch_phif64_l(int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phif64_l(int L, int side, const PhiArgs &a, const PhiLaunch &pl)
 {
-  if (L == 9) { launch_phipk_t<codec_f64, G, 9>(side, a, blocks, st); return true; }      // stands in for p59 rows of 17 elements
-  return launch_phipk_l<codec_f64, G>(L, side, a, blocks, st);
+  if (L == 9) { launch_phipk_t<codec_f64, G, 9>(side, a, pl); return true; }      // stands in for p59 rows of 17 elements
+  return launch_phipk_l<codec_f64, G>(L, side, a, pl);
 }
-bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, uint32_t blocks, hipStream_t st)
+bool launch_phi_packed(int wl, int G, int L, int side, const PhiArgs &a, const PhiLaunch &pl)
 {
   if (wl == WL_F64) {
     switch (G) {
-      case 4:  return launch_phif64_l<4>(L, side, a, blocks, st);
-      case 8:  return launch_phif64_l<8>(L, side, a, blocks, st);
-      case 16: return launch_phif64_l<16>(L, side, a, blocks, st);
-      case 32: return launch_phif64_l<32>(L, side, a, blocks, st);
-      case 64: return launch_phif64_l<64>(L, side, a, blocks, st);
+      case 4:  return launch_phif64_l<4>(L, side, a, pl);
+      case 8:  return launch_phif64_l<8>(L, side, a, pl);
+      case 16: return launch_phif64_l<16>(L, side, a, pl);
+      case 32: return launch_phif64_l<32>(L, side, a, pl);
+      case 64: return launch_phif64_l<64>(L, side, a, pl);
     }
     return false;
   }
-  return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, blocks, st) : launch_phipk_g<codec_f48>(G, L, side, a, blocks, st);
+  return wl == WL_P59 ? launch_phipk_g<codec_p59>(G, L, side, a, pl) : launch_phipk_g<codec_f48>(G, L, side, a, pl);
 }
 
 template <int G>
-bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, const PhiLaunch &pl)
 {
-#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(blocks), dim3(g_phi_wg), 0, st, a, sink); return true;
-  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) }
+#define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(pl.blocks), dim3(pl.wg), 0, pl.st, a, sink); return true;
+  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) GO(12) }
 #undef GO
   return false;
 }
-bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, uint32_t blocks, hipStream_t st)
+// (a row of G lanes x L pieces read by half its lanes IS a row of G/2 lanes x 2L pieces: codec_p59x2)
+bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, const PhiLaunch &pl)
 {
+  if (pl.x2 && G >= 8 && L == 6) { G /= 2; L *= 2; }
   switch (G) {
-    case 4:  return launch_gather_only_l<4>(L, a, sink, blocks, st);
-    case 8:  return launch_gather_only_l<8>(L, a, sink, blocks, st);
-    case 16: return launch_gather_only_l<16>(L, a, sink, blocks, st);
-    case 32: return launch_gather_only_l<32>(L, a, sink, blocks, st);
-    case 64: return launch_gather_only_l<64>(L, a, sink, blocks, st);
+    case 4:  return launch_gather_only_l<4>(L, a, sink, pl);
+    case 8:  return launch_gather_only_l<8>(L, a, sink, pl);
+    case 16: return launch_gather_only_l<16>(L, a, sink, pl);
+    case 32: return launch_gather_only_l<32>(L, a, sink, pl);
+    case 64: return launch_gather_only_l<64>(L, a, sink, pl);
   }
   return false;
 }
@@ -752,7 +799,7 @@ int device_side_work(hpf_handle *h, Side &s, const int64_t *dptr, uint32_t rows)
   s.npartial = 0; s.npartial2 = 0;
   dfree(s.p_idx); dfree(s.p_val); dfree(s.chunks);
   s.p_idx = nullptr; s.p_val = nullptr; s.chunks = nullptr;
-  s.nchunk_blocks = 0; s.tiles = 0; s.tile_rows = 0; s.tiled_nnz = 0; s.light_below = 0;
+  s.nchunk_blocks = 0; s.tiles = 0; s.tile_rows = 0; s.chunk_segs = 0; s.tiled_nnz = 0; s.light_below = 0;
   if (rows == 0) return HPF_OK;
   int rc = HPF_OK;
   uint64_t *cnt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -858,7 +905,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
   // Round 5: with one wave per workgroup on a tiled side (hpf_handle::phi_wg) a run costs less, and the bar of 16 came down
   // to 12 where a batch holds eight nonzeros or fewer (C2 8.42 -> 8.34 ms, a C3 shard 24.3 -> 23.9; 10 is better still at C2
   // and worse on the shard; C4 is flat from 10 to 16; K = 50's two batches of sixteen stay: 24 loses 1 %; experiments.md)
-  const uint32_t per_batch = h->phiG > 0 ? 64u / (uint32_t)h->phiG : 8u;
+  const uint32_t per_batch = h->nz_per_batch();
   const uint32_t min_run = h->tile_min_run ? h->tile_min_run                    // HPF_TILE_RUN: as given
                                            : (per_batch >= 16u ? 2u * per_batch : 12u);
   uint64_t light_below = (uint64_t)tiles * min_run * (tiles < 8 ? 4u : 1u);
@@ -1065,11 +1112,12 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
       for (auto &rg : qt[x]) q[x].push_back(rg);
       if (!front && hi > lo) q[x].push_back({lo, hi});
     }
-    // a launch holds fewer than 2^32 work-items (the AQL packet counts them in 32 bits): at most 2^20 workgroups,
-    // so a list too long for chunks of tile_chunk segments gets longer chunks
-    s.building_tiled = true;
-    const uint32_t wg = h->wg_of(s);
-    s.building_tiled = false;
+    // a launch holds fewer than 2^32 work-items (the AQL packet counts them in 32 bits): at most 2^28 / wg workgroups
+    // (2^20 of four waves, 2^22 of one -- round 5 kept 2^20 for the one-wave groups as well, and the longest lists, whole
+    // C3 or C5 on one GPU, got chunks of 8-16 segments instead of two), so a list too long for chunks of
+    // tile_chunk segments gets longer chunks; hpf_work_info.tile_chunk_user / _item say what was used
+    const uint32_t wg = h->wg_of(true);
+    const size_t max_wgs = ((size_t)1 << 28) / wg;
     uint32_t CH = h->tile_chunk ? h->tile_chunk : 2 * (wg / 64);      // two segments per wave
     // the row-major segments of a side with short rows (users: a few batches each) come in chunks of ~4096 nonzeros:
     // a workgroup that lives for two 40-nonzero rows costs more to dispatch than to run (K = 50, 10^6 light users
@@ -1093,7 +1141,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
         for (auto &rg : q[x]) { const uint32_t ch = chunk_of(rg, CH, CHc); c += (rg.second - rg.first + ch - 1) / ch; }
         worst = std::max(worst, c);
       }
-      if (worst * 8 <= (1u << 20) || CH >= (1u << 30)) break;
+      if (worst * 8 <= max_wgs || CH >= (1u << 30)) break;
     }
     std::vector<uint2> qc[8];
     size_t longest = 0;
@@ -1104,7 +1152,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
       }
       longest = std::max(longest, qc[x].size());
     }
-    if (longest == 0 || longest * 8 > (1u << 20)) break;
+    if (longest == 0 || longest * 8 > max_wgs) break;
     std::vector<uint2> chunks(longest * 8, make_uint2(0u, 0u));
     for (int x = 0; x < 8; ++x) for (size_t j = 0; j < qc[x].size(); ++j) chunks[j * 8 + x] = qc[x][j];
     if ((rc = dalloc(h, &chunks_dev, chunks.size()))) break;
@@ -1121,7 +1169,7 @@ int build_tiled_side(hpf_handle *h, Side &s, const int64_t *ptr, uint32_t rows_o
     s.partial2 = partial2; s.npartial2 = ngroup; partial2 = nullptr;
     s.p_idx = keep_idx; s.p_val = keep_val; keep_idx = nullptr; keep_val = nullptr;
     s.chunks = chunks_dev; s.nchunk_blocks = (uint32_t)chunks.size(); chunks_dev = nullptr;
-    s.tiles = tiles; s.tile_rows = T; s.tiled_nnz = heavy_nnz; s.light_below = light_below;
+    s.tiles = tiles; s.tile_rows = T; s.tiled_nnz = heavy_nnz; s.light_below = light_below; s.chunk_segs = CH;
     (void)tiled_segs;
     done = true;
   } while (0);
@@ -1333,12 +1381,11 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   a.W_own = own.W; a.W_oth = oth.W; a.S_own = own.S; a.partial = own.partial; a.flags = h->flags;
   a.chunks = own.chunks; a.ld = h->ld;
   if (a.nseg) {
-    const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own) / 64 : 4;      // waves per workgroup
+    const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own.chunks != nullptr) / 64 : 4;      // waves per workgroup
     const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
-    g_phi_wg = wpb * 64;
-    const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, blocks, st)
+    const PhiLaunch pl = {blocks, wpb * 64, st, h->phi_waves, h->phi_own_lds, h->phi_x2, h->phi_lds_pad};
+    const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, pl)
                                       : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, st);
-    g_phi_wg = 256;
     if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
   } else if (side == 1) {
     // the item-major pass opens an iteration (phi_pass_skips keeps the books of the fallback protocol): an empty one still does
@@ -1399,7 +1446,38 @@ int run_sweep(hpf_handle *h, Side &s, const double *colsum_oth, double *colsum_o
 // events: 0 start | 1 phi_item kernel done | 2 its combine done |
 //         3 phi_user kernel done | 4 its combine done | 5 user sweep | 6 item sweep
 //         7 start of the replicated half (after whatever exchange the stream waited for)
-int phi_items(hpf_handle *h)
+bool want_graph(const hpf_handle *h);
+void drop_graph(hpf_handle *h);
+int sweep_users(hpf_handle *h);
+int iterate_global(hpf_handle *h);
+
+// the three pieces of a sharded iteration, each captured once (the kernels' arguments stay fixed until the CSR, the rows' layout
+// or the exchange buffer change: drop_graph there).  Piece 1 carries the -novb copy of the old column sums like the eager path.
+int build_split_graphs(hpf_handle *h)
+{
+  for (int k = 0; k < 3; ++k) {
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    int rc = k == 0 ? run_phi(h, h->it, h->u, nullptr) : k == 1 ? run_phi(h, h->u, h->it, nullptr) : iterate_global(h);
+    if (!rc && k == 1) rc = sweep_users(h);
+    h->capturing = false;
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (!rc && e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; }
+    if (!rc) {
+      e = hipGraphInstantiate(&h->split_exec[k], g, nullptr, nullptr, 0);
+      if (e != hipSuccess) { h->split_exec[k] = nullptr; h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); rc = HPF_ERR_HIP; }
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (rc) { drop_graph(h); return rc; }
+  }
+  return HPF_OK;
+}
+// a rank of several replays its pieces under the rule of the one-rank iteration: launch-bound problems (or HPF_GRAPH=1)
+bool split_graph_on(const hpf_handle *h) { return !h->in_recovery && want_graph(h); }
+
+// allow_graph: the caller goes on with hpf_iterate_local_users and hpf_iterate_global -- the cut the graphs are captured along
+int phi_items(hpf_handle *h, bool allow_graph = false)
 {
   int rc;
   if (h->capturing) return run_phi(h, h->it, h->u, nullptr);
@@ -1418,12 +1496,22 @@ int phi_items(hpf_handle *h)
     }
   }
   if ((rc = prepare_derived(h))) return rc;
+  h->tail_partial = false;
   h->ev = h->evr[h->ev_count % hpf_handle::RING];
   h->ring_graphed[h->ev_count % hpf_handle::RING] = false;
+  const bool replay = allow_graph && split_graph_on(h);
+  if (replay && !h->split_exec[0] && (rc = build_split_graphs(h))) return rc;
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;   // step A, beta shape sums
+  if (replay) {
+    // one launch: pass and combines; the per-kernel events coincide (phi_item_ms then holds the whole item half)
+    HIPCHK(h, hipGraphLaunch(h->split_exec[0], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    h->phase = 4;                                            // 4: the pieces of this iteration are graph replays
+  } else {
+    if ((rc = run_phi(h, h->it, h->u, h->ev[1]))) return rc;   // step A, beta shape sums
+    h->phase = 1;
+  }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-  h->phase = 1;
   return HPF_OK;
 }
 
@@ -1464,6 +1552,13 @@ int iterate_local_phi(hpf_handle *h)
 int iterate_local_users(hpf_handle *h)
 {
   int rc;
+  if (h->phase == 4) {                                       // the user half as one graph replay
+    HIPCHK(h, hipGraphLaunch(h->split_exec[1], h->stream));
+    for (int j = 3; j <= 5; ++j) HIPCHK(h, hipEventRecord(h->ev[j], h->stream));
+    h->u.l_stale = h->u.es_stale = true; h->u.w_from_sweep = true;
+    h->phase = 5;
+    return HPF_OK;
+  }
   if ((rc = phi_users(h))) return rc;
   return sweep_users(h);
 }
@@ -1479,9 +1574,12 @@ int iterate_global(hpf_handle *h)
 {
   int rc;
   // steps C (+D item, F): beta rate uses d (all-reduced when n_ranks > 1)
-  if (!h->capturing && h->phase != 3) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
+  if (!h->capturing && h->phase != 3 && h->phase != 5) { h->err = "call order: items pass, users pass, user sweep, iterate_global"; return HPF_ERR_STATE; }
   if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[7], h->stream));
-  if ((rc = run_sweep(h, h->it, h->jacobi ? h->u_colsum_prev : h->u.colsum, h->it.colsum))) return rc;
+  if (!h->capturing && h->phase == 5) {
+    HIPCHK(h, hipGraphLaunch(h->split_exec[2], h->stream));
+    h->it.l_stale = h->it.es_stale = true; h->it.w_from_sweep = true;
+  } else if ((rc = run_sweep(h, h->it, h->jacobi ? h->u_colsum_prev : h->u.colsum, h->it.colsum))) return rc;
   if (h->capturing) return HPF_OK;
   HIPCHK(h, hipEventRecord(h->ev[6], h->stream));
   h->phase = 0;
@@ -1560,6 +1658,7 @@ int recover_flush(hpf_handle *h, uint32_t fl0, uint32_t begun)
 void drop_graph(hpf_handle *h)
 {
   if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  for (int k = 0; k < 3; ++k) if (h->split_exec[k]) { (void)hipGraphExecDestroy(h->split_exec[k]); h->split_exec[k] = nullptr; }
 }
 
 bool want_graph(const hpf_handle *h)
@@ -1799,6 +1898,10 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_TILE_SHARE")) { int v = atoi(e); if (v >= 0 && v <= 100) h->tile_min_share = v / 100.0; }
   if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
   if (const char *e = knob("HPF_PHI_WG")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) h->phi_wg = (uint32_t)v; }
+  if (const char *e = knob("HPF_PHI_WAVES")) { int v = atoi(e); if (v == 3 || v == 4) h->phi_waves = v; }
+  if (const char *e = knob("HPF_PHI_OWN_LDS")) h->phi_own_lds = atoi(e) != 0;
+  if (const char *e = knob("HPF_PHI_X2")) h->phi_x2 = atoi(e) != 0;
+  if (const char *e = knob("HPF_PHI_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 160 * 1024) h->phi_lds_pad = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
   h->u.rows = n; h->it.rows = m;
@@ -1865,6 +1968,7 @@ void hpf_destroy(hpf_handle *h)
   dfree(icol);
   if (!h->exch_external) dfree(h->exch);
   dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->colptr_dev); dfree(h->flags); dfree(h->u_colsum_prev);
+  for (int k = 0; k < HPF_HELDOUT_SLOTS; ++k) free_held(h->held[k]);
   for (int k = 0; k < 2; ++k) {
     if (h->stage[k]) (void)hipHostFree(h->stage[k]);
     if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
@@ -1913,7 +2017,7 @@ int hpf_allreduce_items_begin(hpf_handle *h)
 {
   if (!h) return HPF_ERR_INVALID;
   if (!h->comm) { h->err = "hpf_comm_init has not been called"; return HPF_ERR_STATE; }
-  if (h->phase != 1) { h->err = "hpf_allreduce_items_begin follows hpf_iterate_local_items"; return HPF_ERR_STATE; }
+  if (h->phase != 1 && h->phase != 4) { h->err = "hpf_allreduce_items_begin follows hpf_iterate_local_items"; return HPF_ERR_STATE; }
   if (!h->comm_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
@@ -1968,6 +2072,7 @@ int hpf_start_sums(hpf_handle *h)
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));     // the caller's all-reduce may run on another stream
   h->start_sums_done = true;
+  h->tail_partial = !h->comm;
   return HPF_OK;
 }
 
@@ -2266,8 +2371,9 @@ int hpf_get_state_device(hpf_handle *h, hpf_state which, double *dev, size_t cou
 
 // ---- snapshot: the loop's device state, verbatim -------------------------------
 namespace {
+constexpr char SNAP_MAGIC[9] = "HPFSNAP4";
 struct SnapHeader {
-  char magic[8];                        // "HPFSNAP3"
+  char magic[8];                        // "HPFSNAP4" (round 6: the order of a p59 lane's dwords changed, and the header carries sums_dirty / start_sums_done)
   uint32_t n_users, n_items, K, ld, hier, bias, w32, iterations;
   // what else the state is only meaningful with: the priors, the job's shape and
   // the ratings it was fitted to -- a snapshot of another data set of the same dimensions,
@@ -2277,7 +2383,9 @@ struct SnapHeader {
   double s_prior, r_prior;
   uint32_t side_flags[2];               // bit 0 have_E, 1 have_L, 2 have_prior, 3 w_dirty, 4 l_stale, 5 es_stale,
                                         // 6 rate_set present, 7 prior_shape_set present
-  uint32_t derived_dirty, pad;
+  uint32_t derived_dirty;
+  uint32_t more_flags;                  // bit 0 sums_dirty, bit 1 start_sums_done (a handle whose W alone was pending must not
+                                        // come back as one whose start sums are pending -- on several ranks it would enter a collective alone)
   uint64_t rate_set_count[2];
   uint64_t total_bytes;
 };
@@ -2307,7 +2415,7 @@ uint32_t side_flag_word(const Side &s)
 void fill_snap_header(hpf_handle *h, SnapHeader *hd)
 {
   memset(hd, 0, sizeof *hd);
-  memcpy(hd->magic, "HPFSNAP3", 8);
+  memcpy(hd->magic, SNAP_MAGIC, 8);
   hd->n_users = h->u.rows; hd->n_items = h->it.rows; hd->K = h->K; hd->ld = h->ld;
   hd->hier = h->cfg.hier; hd->bias = h->cfg.bias; hd->w32 = h->cfg.w_storage | ((uint32_t)h->wl << 8); hd->iterations = h->iterations;   // storage mode and the row layout in use
   hd->n_users_total = h->cfg.n_users_total; hd->rank = h->cfg.rank; hd->n_ranks = h->cfg.n_ranks;
@@ -2315,6 +2423,7 @@ void fill_snap_header(hpf_handle *h, SnapHeader *hd)
   hd->s_prior = h->cfg.s_prior; hd->r_prior = h->cfg.r_prior;
   hd->side_flags[0] = side_flag_word(h->u); hd->side_flags[1] = side_flag_word(h->it);
   hd->derived_dirty = h->derived_dirty;
+  hd->more_flags = (h->sums_dirty ? 1u : 0u) | (h->start_sums_done ? 2u : 0u);
   hd->rate_set_count[0] = h->u.rate_set ? h->u.rate_set_count : 0;
   hd->rate_set_count[1] = h->it.rate_set ? h->it.rate_set_count : 0;
   std::vector<SnapSection> sec;
@@ -2360,10 +2469,10 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
   SnapHeader hd; memcpy(&hd, host, sizeof hd);
   // a snapshot taken after the rows fell back to plain doubles loads into a handle that still packs them: same job, the
   // handle follows (validated below like everything else, but the layout has to be known to size the sections)
-  const bool follow = !memcmp(hd.magic, "HPFSNAP3", 8) && h->wl == WL_P59 && hd.w32 == (h->cfg.w_storage | ((uint32_t)WL_F64 << 8)) &&
+  const bool follow = !memcmp(hd.magic, SNAP_MAGIC, 8) && h->wl == WL_P59 && hd.w32 == (h->cfg.w_storage | ((uint32_t)WL_F64 << 8)) &&
                       hd.n_users == h->u.rows && hd.n_items == h->it.rows && hd.K == h->K && hd.ld == h->ld && hd.total_bytes == bytes;
   if (follow) { int rc0 = recover_if_flushed(h); if (!rc0 && h->wl == WL_P59) rc0 = set_rows_f64(h); if (rc0) return rc0; h->fallbacks++; }
-  if (memcmp(hd.magic, "HPFSNAP3", 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
+  if (memcmp(hd.magic, SNAP_MAGIC, 8) || hd.total_bytes != bytes || hd.n_users != h->u.rows || hd.n_items != h->it.rows ||
       hd.K != h->K || hd.ld != h->ld || hd.hier != h->cfg.hier || hd.bias != h->cfg.bias || hd.w32 != (h->cfg.w_storage | ((uint32_t)h->wl << 8))) {
     h->err = "not a snapshot of this model (shape, flags or storage differ)"; return HPF_ERR_INVALID;
   }
@@ -2417,8 +2526,9 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
     s.have_E = f & 1u; s.have_L = f & 2u; s.have_prior = f & 4u; s.w_dirty = f & 8u; s.l_stale = f & 16u; s.es_stale = f & 32u;
     s.w_from_sweep = (f & 256u) != 0;
   }
-  h->derived_dirty = h->sums_dirty = hd.derived_dirty != 0;
-  h->start_sums_done = !h->derived_dirty;      // the tail of the exchange buffer came with the snapshot
+  h->derived_dirty = hd.derived_dirty != 0;
+  h->sums_dirty = (hd.more_flags & 1u) != 0;
+  h->start_sums_done = (hd.more_flags & 2u) != 0;      // the tail of the exchange buffer came with the snapshot
   h->iterations = hd.iterations;
   h->phase = 0;
   HIPCHK(h, hipMemsetAsync(h->flags, 0, 8, h->stream));
@@ -2430,12 +2540,13 @@ int hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes)
 int hpf_iterate(hpf_handle *h, int n_iters)
 {
   if (!h || n_iters < 0) return HPF_ERR_INVALID;
-  if (h->cfg.n_ranks != 1) {
-    // several ranks: whole iterations only when the library owns the exchange
+  if (h->cfg.n_ranks != 1 || h->comm) {
+    // several ranks -- or one with a communicator of its own (a one-rank RCCL communicator: tests, bench.py --comm library on one
+    // GPU) --: whole iterations only when the library owns the exchange
     if (!h->comm) { h->err = "hpf_iterate with n_ranks > 1 needs hpf_comm_init (or use iterate_local / your all-reduce / iterate_global)"; return HPF_ERR_INVALID; }
     for (int t = 0; t < n_iters; ++t) {
       int rc;
-      if ((rc = phi_items(h))) return rc;
+      if ((rc = phi_items(h, true))) return rc;
       if ((rc = hpf_allreduce_items_begin(h))) return rc;
       if ((rc = iterate_local_users(h))) return rc;
       if ((rc = hpf_allreduce_exchange(h))) return rc;
@@ -2455,9 +2566,37 @@ int hpf_iterate(hpf_handle *h, int n_iters)
 int hpf_iterate_local(hpf_handle *h) { return h ? iterate_local(h) : HPF_ERR_INVALID; }
 int hpf_iterate_local_phi(hpf_handle *h) { return h ? iterate_local_phi(h) : HPF_ERR_INVALID; }
 int hpf_iterate_local_sweep(hpf_handle *h) { return h ? sweep_users(h) : HPF_ERR_INVALID; }
-int hpf_iterate_local_items(hpf_handle *h) { return h ? phi_items(h) : HPF_ERR_INVALID; }
+int hpf_iterate_local_items(hpf_handle *h) { return h ? phi_items(h, true) : HPF_ERR_INVALID; }
 int hpf_iterate_local_users(hpf_handle *h) { return h ? iterate_local_users(h) : HPF_ERR_INVALID; }
 int hpf_iterate_global(hpf_handle *h) { return h ? iterate_global(h) : HPF_ERR_INVALID; }
+
+namespace {
+// per-pair log-likelihoods of cnt pairs whose indices lie on the device, into hout (host; page-locked for a bound set),
+// summed serially in the order handed in: the map order of hgaprec.cc:1455-1465
+int heldout_run(hpf_handle *h, const uint32_t *du, const uint32_t *di, const int32_t *dy, double *dout, double *hout, size_t cnt,
+                double *sum_out)
+{
+  int rc;
+  if ((rc = check_flags(h))) return rc;
+  if ((rc = refresh_es(h, h->u)) || (rc = refresh_es(h, h->it))) return rc;
+  LLArgs a;
+  a.u = du; a.i = di; a.y = dy; a.cnt = cnt; a.Et = h->u.E; a.Eb = h->it.E;
+  a.logfact = h->logfact; a.out = dout; a.ld = h->ld; a.K = h->K;
+  a.ubias_col = h->cfg.bias ? h->u.bias_col : -1;
+  a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
+  a.binary = h->cfg.binary;
+  const uint32_t blocks = (uint32_t)std::min<size_t>((cnt + 15) / 16, 4096);
+  hipLaunchKernelGGL(heldout_ll_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+  if ((rc = check_launch(h, "heldout_ll"))) return rc;
+  hipError_t e = hipMemcpyAsync(hout, dout, cnt * 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
+  double s = .0;
+  for (size_t p = 0; p < cnt; ++p) s += hout[p];
+  *sum_out = s;
+  return HPF_OK;
+}
+}  // namespace
 
 int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const int32_t *y,
                    size_t cnt, double *sum_out, uint64_t *cnt_out)
@@ -2471,8 +2610,6 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     if (u[p] >= h->u.rows || i[p] >= h->it.rows) { h->err = "held-out index out of range"; return HPF_ERR_INVALID; }
   uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr;
   int rc = HPF_OK;
-  if ((rc = check_flags(h))) return rc;
-  if ((rc = refresh_es(h, h->u)) || (rc = refresh_es(h, h->it))) return rc;
   std::vector<double> out(cnt);
   do {
     if ((rc = dalloc(h, &du, cnt)) || (rc = dalloc(h, &di, cnt)) || (rc = dalloc(h, &dy, cnt)) ||
@@ -2481,24 +2618,42 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     if (e == hipSuccess) e = hipMemcpyAsync(di, i, cnt * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dy, y, cnt * 4, hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
-    LLArgs a;
-    a.u = du; a.i = di; a.y = dy; a.cnt = cnt; a.Et = h->u.E; a.Eb = h->it.E;
-    a.logfact = h->logfact; a.out = dout; a.ld = h->ld; a.K = h->K;
-    a.ubias_col = h->cfg.bias ? h->u.bias_col : -1;
-    a.ibias_col = h->cfg.bias ? h->it.bias_col : -1;
-    a.binary = h->cfg.binary;
-    const uint32_t blocks = (uint32_t)std::min<size_t>((cnt + 15) / 16, 4096);
-    hipLaunchKernelGGL(heldout_ll_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
-    if ((rc = check_launch(h, "heldout_ll"))) break;
-    e = hipMemcpyAsync(out.data(), dout, cnt * 8, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
-    double s = .0;                       // serial, in map order: hgaprec.cc:1455-1465
-    for (size_t p = 0; p < cnt; ++p) s += out[p];
-    *sum_out = s;
+    rc = heldout_run(h, du, di, dy, dout, out.data(), cnt, sum_out);
   } while (0);
   dfree(du); dfree(di); dfree(dy); dfree(dout);
   return rc;
+}
+
+// A report step evaluates the SAME validation and test pairs every time (hgaprec.cc:1439-1470 walks the same two maps):
+// bound once, a set is validated and uploaded once, and hpf_heldout_ll_bound is the kernel, one DMA of the per-pair
+// values into a kept page-locked buffer and the ordered host sum -- the same sum, bit for bit, as hpf_heldout_ll's.
+int hpf_heldout_bind(hpf_handle *h, int slot, const uint32_t *u, const uint32_t *i, const int32_t *y, size_t cnt)
+{
+  if (!h || slot < 0 || slot >= HPF_HELDOUT_SLOTS) return HPF_ERR_INVALID;
+  if (cnt && (!u || !i || !y)) return HPF_ERR_INVALID;
+  for (size_t p = 0; p < cnt; ++p)
+    if (u[p] >= h->u.rows || i[p] >= h->it.rows) { h->err = "held-out index out of range"; return HPF_ERR_INVALID; }
+  hpf_handle::HeldSet &hs = h->held[slot];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_held(hs);
+  hs.cnt = cnt; hs.bound = true;
+  if (cnt == 0) return HPF_OK;
+  int rc;
+  if ((rc = dalloc(h, &hs.du, cnt)) || (rc = dalloc(h, &hs.di, cnt)) || (rc = dalloc(h, &hs.dy, cnt)) || (rc = dalloc(h, &hs.dout, cnt))) { free_held(hs); return rc; }
+  if (hipHostMalloc((void **)&hs.hout, cnt * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); free_held(hs); h->err = "hpf_heldout_bind: no page-locked memory"; return HPF_ERR_OOM; }
+  if ((rc = h2d(h, hs.du, u, cnt * 4)) || (rc = h2d(h, hs.di, i, cnt * 4)) || (rc = h2d(h, hs.dy, y, cnt * 4))) { free_held(hs); return rc; }
+  return HPF_OK;
+}
+
+int hpf_heldout_ll_bound(hpf_handle *h, int slot, double *sum_out, uint64_t *cnt_out)
+{
+  if (!h || !sum_out || slot < 0 || slot >= HPF_HELDOUT_SLOTS) return HPF_ERR_INVALID;
+  const hpf_handle::HeldSet &hs = h->held[slot];
+  if (!hs.bound) { h->err = "hpf_heldout_ll_bound: nothing bound to this slot"; return HPF_ERR_STATE; }
+  *sum_out = 0.0; if (cnt_out) *cnt_out = hs.cnt;
+  if (hs.cnt == 0) return HPF_OK;
+  if (!(h->u.have_E && h->it.have_E) && h->iterations == 0) { h->err = "E state not set"; return HPF_ERR_STATE; }
+  return heldout_run(h, hs.du, hs.di, hs.dy, hs.dout, hs.hout, hs.cnt, sum_out);
 }
 
 int hpf_elbo(hpf_handle *h, double *out)
@@ -2729,8 +2884,14 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->heavy_min_nnz_user = h->u.tiles ? h->u.light_below : 0; out->heavy_min_nnz_item = h->it.tiles ? h->it.light_below : 0;
   out->w_fallbacks = h->fallbacks;
   out->notes = h->notes;
-  out->start_sums_pending = (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done)) ? 1u : 0u;
-  out->graph_replay = (h->have_csr && h->cfg.n_ranks == 1 && want_graph(h)) ? 1u : 0u;
+  out->start_sums_pending = (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done || h->tail_partial)) ? 1u : 0u;
+  out->graph_replay = (h->have_csr && want_graph(h)) ? ((h->cfg.n_ranks == 1 && !h->comm) ? 1u : 2u) : 0u;
+  out->tile_chunk_user = h->u.chunks ? h->u.chunk_segs : 0; out->tile_chunk_item = h->it.chunks ? h->it.chunk_segs : 0;
+  {
+    const bool six = h->wl == WL_P59 && h->phiR == 6;                 // the shapes the other builds exist for (launch_phipk_t)
+    const bool x2 = six && h->phi_x2 && h->phiG >= 8;
+    out->phi_build = six ? (uint32_t)(x2 ? 2 : h->phi_waves) | (h->phi_own_lds ? 16u : 0u) | (x2 ? 32u : 0u) : 3u;
+  }
   return HPF_OK;
 }
 
@@ -2751,23 +2912,22 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if (!a.nseg) return HPF_OK;
   uint32_t *sink = nullptr;
   if ((rc = dalloc(h, &sink, 1))) return rc;
-  const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own) / 64 : 4;        // the pass's own workgroups (run_phi)
+  const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own.chunks != nullptr) / 64 : 4;        // the pass's own workgroups (run_phi)
   const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
-  g_phi_wg = wpb * 64;
+  const PhiLaunch pl = {blocks, wpb * 64, h->stream, h->phi_waves, h->phi_own_lds, h->wl == WL_P59 ? h->phi_x2 : 0, 0u};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
-  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);      // warm-up
+  bool ok = e == hipSuccess && launch_gather_only(h->phiG, h->phiR, a, sink, pl);      // warm-up
   if (ok) {
     e = hipEventRecord(e0, h->stream);
-    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, a, sink, blocks, h->stream);
+    for (int r = 0; r < reps && ok; ++r) ok = launch_gather_only(h->phiG, h->phiR, a, sink, pl);
     if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / (float)reps;
   }
-  g_phi_wg = 256;
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   dfree(sink);

@@ -18,6 +18,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Build-time switches (A/B builds of tools/ and profiles/ only; the library ships the defaults)
+#ifndef HPF_P59_PAIRED
+#define HPF_P59_PAIRED 1       // order of a p59 lane's dwords: 1 = (low word, stream dword) pairs (round 6), 0 = round 5's
+#endif
+
 namespace hpf {
 
 // ---------------------------------------------------------------------
@@ -333,6 +338,7 @@ enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3, WL_F64 = 4 };      // layout codes 
 template <int L> struct codec_f64 {
   static constexpr int E = 2 * L;
   static constexpr bool fixed_ld = false;
+  static constexpr __device__ int col(int e, int G) { return e * G; }   // column of element slot e in lane 0 of a G-lane group
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
   {
     return __hiloint2double((int)d[2 * e + 1], (int)d[2 * e]);
@@ -341,6 +347,7 @@ template <int L> struct codec_f64 {
 
 template <int L> struct codec_f48 {
   static constexpr bool fixed_ld = true;
+  static constexpr __device__ int col(int e, int G) { return e * G; }
   static constexpr int E = (8 * L) / 3;                   // 2 5 8 10 13 16 18 21
   static_assert(E + (E + 1) / 2 <= 4 * L, "lane dwords overflow");
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
@@ -352,15 +359,30 @@ template <int L> struct codec_f48 {
 
 template <int L> struct codec_p59 {
   static constexpr bool fixed_ld = true;
+  static constexpr __device__ int col(int e, int G) { return e * G; }
   static constexpr int E = (128 * L) / 59;                // 2 4 6 8 10 13 15 17
-  static_assert(E + (27 * E + 31) / 32 <= 4 * L, "lane dwords overflow");
+  static constexpr int S = (27 * E + 31) / 32;            // dwords of the field stream
+  static_assert(E + S <= 4 * L, "lane dwords overflow");
+  // Place of logical dword k among the lane's 4L (k < E: low word of element k; k >= E: dword k - E of the field stream).
+  // Round 6: PAIRED -- the low word of element e sits at the even place 2e and stream dword j at the odd place 2j + 1 (the
+  // E - 2L low words that find no even place take the odd places the stream leaves free).  A decoded element is the register
+  // PAIR (low word, high word) and the high word is computed from the stream: with the low word in an even register and a
+  // stream dword that is dead by then beside it, the pair is formed in place -- the elements are decoded from the last to the
+  // first, so that stream dword e has been consumed by the elements above e when element e overwrites it.  In the round-5
+  // order (all low words, then the stream) every other low word had to be copied into a fresh pair first: 11 v_mov per batch
+  // of 93 VALU instructions and 12 more registers (tools/count_isa.py; profiles/r06/experiments.md 1).
+  static constexpr __host__ __device__ int pos(int k)
+  {
+    if (!HPF_P59_PAIRED) return k;
+    return k < E ? (k < 2 * L ? 2 * k : 2 * (S + k - 2 * L) + 1) : 2 * (k - E) + 1;
+  }
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
   {
     const int o = 27 * e, i = E + o / 32, sh = o % 32;    // compile-time after unrolling
     uint32_t f;
-    if (sh == 0) f = d[i];
-    else if (sh + 27 <= 32) f = d[i] >> sh;
-    else f = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+    if (sh == 0) f = d[pos(i)];
+    else if (sh + 27 <= 32) f = d[pos(i)] >> sh;
+    else f = __builtin_amdgcn_alignbit(d[pos(i + 1)], d[pos(i)], sh);
     // exponent field + 896.  The all-zero element (padding columns, a flushed entry) decodes to
     // 2^-127 = 5.9e-39 instead of 0 -- no compare and two selects per element: products of two such
     // entries are 3e-77, below any sum they could join by sixty orders.  Mask and bias in ONE
@@ -368,7 +390,34 @@ template <int L> struct codec_p59 {
     // a VGPR (the compiler left to itself emits v_and + v_or with literals)
     uint32_t hi;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(f), "s"(0x7ffffffu), "v"(0x38000000u));
-    return __hiloint2double((int)hi, (int)d[e]);
+    return __hiloint2double((int)hi, (int)d[pos(e)]);
+  }
+};
+
+// p59 rows read by HALF as many lanes (round 6).  A row laid out for GV lanes of L1 pieces is, byte for byte, a row of
+// GV/2 lanes of 2 L1 pieces: piece t of virtual lane v = h GV/2 + g sits at byte ((2t + h) GV/2 + g) 16 -- piece 2t + h of
+// physical lane g.  A physical lane thus holds the dword streams of its two virtual lanes h = 0, 1 interleaved piece by
+// piece and decodes 2 E1 elements: slot e = h E1 + e1 is column e1 GV + h GV/2 + g.  Nothing about the stored rows, the
+// sweep or S changes; a batch holds twice the nonzeros and the group sum, the reciprocal and the addresses of a nonzero are
+// paid by half the lanes (K = 200: 8 lanes x 12 pieces over rows laid out (16, 6)).  L = pieces per PHYSICAL lane.
+template <int L> struct codec_p59x2 {
+  static_assert(L % 2 == 0, "two virtual lanes per physical lane");
+  using C1 = codec_p59<L / 2>;
+  static constexpr bool fixed_ld = true;
+  static constexpr int E1 = C1::E, E = 2 * E1;
+  static constexpr __device__ int col(int e, int G) { return (e % E1) * 2 * G + (e / E1) * G; }
+  static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
+  {
+    const int h = e / E1, e1 = e % E1;
+    const int o = 27 * e1, i = E1 + o / 32, sh = o % 32;
+    auto at = [&](int k) -> uint32_t { const int q = C1::pos(k); return d[4 * ((q / 4) * 2 + h) + q % 4]; };
+    uint32_t f;
+    if (sh == 0) f = at(i);
+    else if (sh + 27 <= 32) f = at(i) >> sh;
+    else f = __builtin_amdgcn_alignbit(at(i + 1), at(i), sh);
+    uint32_t hi;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(f), "s"(0x7ffffffu), "v"(0x38000000u));
+    return __hiloint2double((int)hi, (int)at(e1));
   }
 };
 
@@ -387,6 +436,14 @@ __device__ __forceinline__ void packed_clear(uint32_t *buf, const PackedRow &pk,
   for (uint32_t d = li; d < pk.row_bytes / 4; d += nl) buf[d] = 0u;
 }
 
+// codec_p59<L>::pos at run time (the LDS writers take the shape from PackedRow)
+__device__ __forceinline__ uint32_t p59_pos(const PackedRow &pk, uint32_t k)
+{
+  if (!HPF_P59_PAIRED) return k;
+  const uint32_t S = (27u * pk.E + 31u) / 32u;
+  return k < pk.E ? (k < 2u * pk.L ? 2u * k : 2u * (S + k - 2u * pk.L) + 1u) : 2u * (k - pk.E) + 1u;
+}
+
 // returns true when a nonzero w had to be flushed (below 2^-126)
 __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint32_t c, double w)
 {
@@ -397,11 +454,11 @@ __device__ __forceinline__ bool p59_put(uint32_t *buf, const PackedRow &pk, uint
   // the all-zero element; only an exact +0 does so without being reported
   const bool tiny = hi < 0x38100000u || hi >= 0x40000000u;
   const uint32_t f = tiny ? 0u : hi - 0x38000000u;
-  buf[packed_dword_index(pk, g, e)] = tiny ? 0u : lo;
+  buf[packed_dword_index(pk, g, p59_pos(pk, e))] = tiny ? 0u : lo;
   const uint32_t o = 27u * e, i = pk.E + o / 32u, sh = o % 32u;
   if (f) {
-    atomicOr(&buf[packed_dword_index(pk, g, i)], f << sh);
-    if (sh > 5u) atomicOr(&buf[packed_dword_index(pk, g, i + 1)], f >> (32u - sh));
+    atomicOr(&buf[packed_dword_index(pk, g, p59_pos(pk, i))], f << sh);
+    if (sh > 5u) atomicOr(&buf[packed_dword_index(pk, g, p59_pos(pk, i + 1))], f >> (32u - sh));
   }
   return tiny && !(hi == 0u && lo == 0u);
 }
@@ -432,16 +489,25 @@ __device__ __forceinline__ void f64_put(void *W, size_t row, const PackedRow &pk
   d[((((e >> 1) << pk.lgG) + g) << 1) + (e & 1u)] = w;
 }
 
-template <class OthC, int E, int G, int LT>
-__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[E],
+// OWN_LDS: the owner's factors are read from LDS (own_l + e * G: this lane's column of element slot e) instead of from
+// E register pairs (phi_segments)
+typedef __attribute__((address_space(3))) double lds_double;      // a pointer that stays an LDS pointer (ds_read / ds_write) through inline asm
+template <class OthC, int E, int G, int LT, bool OWN_LDS>
+__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[OWN_LDS ? 1 : E], const lds_double *own_l,
                                                  double (&acc)[E], float yf, bool &underflow)
 {
   double xv[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) xv[e] = OthC::get(x, e);
+  for (int e = E - 1; e >= 0; --e) xv[e] = OthC::get(x, e);     // last to first: codec_p59::pos
+  // (the empty asm hides from the compiler that the address is the same in every batch: left visible, the loads are hoisted
+  // out of the batch loop and the factors are back in registers -- or in scratch)
+  if (OWN_LDS) asm volatile("" : "+v"(own_l));
   double s[2] = {0.0, 0.0};
 #pragma unroll
-  for (int e = 0; e < E; ++e) s[e & 1] = (e < 2) ? own[e] * xv[e] : fma(own[e], xv[e], s[e & 1]);
+  for (int e = 0; e < E; ++e) {
+    const double o = OWN_LDS ? own_l[e * G] : own[OWN_LDS ? 0 : e];
+    s[e & 1] = (e < 2) ? o * xv[e] : fma(o, xv[e], s[e & 1]);
+  }
   const double ssum = group_sum<G>((E > 1) ? s[0] + s[1] : s[0]);
   const double yy = (double)yf;
   const bool ok = ssum > 0.0;
@@ -455,9 +521,11 @@ __device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], co
 // lane), the gathered rows in OthC's (LT pieces).  E = OwnC::E element slots are worked on (OthC::E >= E; the
 // library only instantiates OwnC = OthC -- the two-layout form is what the fp64-shadow experiment of round 4
 // ran on, profiles/r04/experiments.md 1).  W_own / W_oth already point at this lane's first piece.
-template <class OwnC, class OthC, int G, int LO, int LT>
+// OWN_LDS (round 6): the owner's decoded factors live in LDS -- own_l, G * E doubles of this wave, element slot e of lane
+// g at e * G + g -- instead of in E register pairs: the registers that frees are what a fourth wave per SIMD needs.
+template <class OwnC, class OthC, int G, int LO, int LT, bool OWN_LDS = false>
 __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &sr, const unsigned char *W_own,
-                                             const unsigned char *W_oth, int lane, bool &underflow)
+                                             const unsigned char *W_oth, int lane, bool &underflow, lds_double *own_l = nullptr)
 {
   constexpr int NG = 64 / G;
   constexpr int E = OwnC::E;
@@ -528,29 +596,42 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       cur_i = nxt_i; cur_y = nxt_y;
       fetch_after(b / G);
     };
-    double own[E], acc[E];
+    double own[OWN_LDS ? 1 : E], acc[E];
     {
       uint32_t r[4 * LO];
       load_own(r, W_own + (size_t)sg.row * ROWO);
       gather(xa, ya, 0);          // unconditional (a conditional gather costs copies and waits): past the
       gather(xb, yb, 1);          // segment's end the index reads 0 -- row 0, loaded and never used
       fetch_after(0);
+      if constexpr (OWN_LDS) {
+        // the previous segment's reads of own_l are behind us in program order and the LDS serves a wave's instructions in
+        // order; the barriers only keep the compiler from moving the accesses of other lanes' words across each other
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int e = 0; e < E; ++e) { own[e] = OwnC::get(r, e); acc[e] = 0.0; }
+        for (int e = E - 1; e >= 0; --e) { const double o = OwnC::get(r, e); if (q == 0) own_l[e * G + g] = o; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.0;
+      } else {
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) { own[OWN_LDS ? 0 : e] = OwnC::get(r, e); acc[e] = 0.0; }
+      }
     }
+    const lds_double *own_g = OWN_LDS ? own_l + g : nullptr;
     if (len > 0) {
       // same schedule as phi_pass_kernel: two register sets, peeled tail
       uint32_t bb = 0;
       for (; bb + 3 < nb; bb += 2) {
-        phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
         __builtin_amdgcn_sched_barrier(0);
         if (((bb + 2) % G) == 0) next_chunk(bb + 2);
         gather(xa, ya, bb + 2);
-        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
+        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xb, own, own_g, acc, yb, underflow);
         __builtin_amdgcn_sched_barrier(0);
         gather(xb, yb, bb + 3);
       }
-      phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
+      phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
       if (bb + 1 < nb) {
         const bool third = bb + 2 < nb;
         __builtin_amdgcn_sched_barrier(0);
@@ -558,8 +639,8 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
           if (((bb + 2) % G) == 0) next_chunk(bb + 2);
           gather(xa, ya, bb + 2);
         }
-        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
-        if (third) phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xb, own, own_g, acc, yb, underflow);
+        if (third) phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
       }
     }
     double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + g;
@@ -570,20 +651,26 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       if (G <= 16) r += __shfl_xor(r, 16, 64);
       if (G <= 8)  r += __shfl_xor(r, 8, 64);
       if (G <= 4)  r += __shfl_xor(r, 4, 64);
-      if (q == 0 && (OwnC::fixed_ld || (uint32_t)(e * G + g) < LD)) dst[(size_t)e * G] = own[e] * r;
+      const double o = OWN_LDS ? own_g[e * G] : own[OWN_LDS ? 0 : e];
+      if (q == 0 && (OwnC::fixed_ld || (uint32_t)(OwnC::col(e, G) + g) < LD)) dst[(size_t)OwnC::col(e, G)] = o * r;
     }
   }
 }
 
-template <template <int> class CodecT, int G, int L, int SIDE>
-__global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
+// WAVES: waves per SIMD the register allocation is held to (3: 168 VGPRs, 4: 128, 2: 256); OWN: the owner's factors in LDS
+// (phi_segments).  SIDE stays the last template argument: the profiles tell the passes apart by it.
+template <template <int> class CodecT, int G, int L, int WAVES, int OWN, int SIDE>
+__global__ __launch_bounds__(256, WAVES) void phi_pass_packed_kernel(PhiArgs a)
 {
+  constexpr int E = CodecT<L>::E;
+  __shared__ double own_sh[OWN ? 4 * G * E : 1];      // a row of decoded factors per wave of the workgroup
   if (phi_pass_skips(a, SIDE)) return;
   const int lane = threadIdx.x & 63;
   const SegRange sr = seg_range(a);
   bool underflow = false;
-  phi_segments<CodecT<L>, CodecT<L>, G, L, L>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
-                                              (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, underflow);
+  phi_segments<CodecT<L>, CodecT<L>, G, L, L, OWN != 0>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
+                                                        (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, underflow,
+                                                        (lds_double *)own_sh + (OWN ? (threadIdx.x >> 6) * (G * E) : 0));
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 
@@ -945,10 +1032,11 @@ template <int R> struct p59_of_slots {
 template <int E, int L>
 __device__ __forceinline__ void p59_place(uint32_t (&D)[4 * L], int e, uint32_t lo, uint32_t f)
 {
+  using C = codec_p59<L>;
   const int o = 27 * e, i = E + o / 32, sh = o % 32;
-  D[e] = lo;
-  D[i] |= f << sh;
-  if (sh > 5) D[i + 1] |= f >> (32 - sh);
+  D[C::pos(e)] = lo;
+  D[C::pos(i)] |= f << sh;
+  if (sh > 5) D[C::pos(i + 1)] |= f >> (32 - sh);
 }
 
 // MODE = SW_PLAIN: W is stored as double (or float, a.w32) and the row stride IS G*R (hpf_create): no column test.

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPF_ABI_VERSION 7
+#define HPF_ABI_VERSION 8
 
 typedef struct hpf_handle hpf_handle;
 
@@ -208,7 +208,9 @@ int  hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes);
  * Launch-bound problems (nnz <= 4 Mi, or HPF_GRAPH=1; HPF_GRAPH=0 disables)
  * replay one captured iteration as a hipGraph: same kernels in the same
  * order, identical bits; such iterations report only iteration_ms in
- * hpf_timing (the per-kernel fields read 0). */
+ * hpf_timing (the per-kernel fields read 0).  With n_ranks > 1 (or a communicator)
+ * the same rule replays the iteration as THREE graphs -- item pass | user pass + user
+ * sweep | item sweep -- around the two collectives (v8; hpf_work_info.graph_replay = 2). */
 int  hpf_iterate(hpf_handle *h, int n_iters);
 
 /* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,
@@ -248,8 +250,9 @@ int  hpf_iterate_global(hpf_handle *h);
  * rank's part of that sum in the tail of the exchange buffer (its last `ld` doubles,
  * hpf_work_info.ld).  With hpf_comm_init done it also all-reduces the tail itself (and hpf_iterate
  * calls it on its own); otherwise the caller sum-all-reduces those ld doubles in place, like the
- * per-iteration exchange -- but ONLY when hpf_work_info.start_sums_pending read 1 before the call: after
- * hpf_snapshot_load the tail is the reduced sum already (v7).  Call it after the last hpf_set_state /
+ * per-iteration exchange -- but ONLY when hpf_work_info.start_sums_pending reads 1: after
+ * hpf_snapshot_load the tail is the reduced sum already (v7).  From v8 on the field may be read before OR after the call:
+ * it keeps reading 1 while the tail holds this rank's part only, until the first pass of the next iteration.  Call it after the last hpf_set_state /
  * hpf_snapshot_load and before the first hpf_iterate_local_*: iterating without it returns
  * HPF_ERR_STATE.  A no-op elsewhere. */
 int  hpf_start_sums(hpf_handle *h);
@@ -282,6 +285,14 @@ int  hpf_exchange_write(hpf_handle *h, const double *host, size_t count);
 int  hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i,
                     const int32_t *y, size_t cnt, double *sum_out,
                     uint64_t *cnt_out);
+/* ABI v8.  A report step evaluates the same validation and test pairs every time (hgaprec.cc:1439-1470 walks the same
+ * two maps): hpf_heldout_bind validates and uploads a set ONCE into one of HPF_HELDOUT_SLOTS slots (binding again
+ * replaces it; cnt = 0 binds an empty set); hpf_heldout_ll_bound is then the kernel, one DMA of the per-pair values
+ * into a page-locked buffer the handle keeps, and the same serial sum in the order the pairs were bound -- the value
+ * hpf_heldout_ll returns for the same pairs, bit for bit.  The caller's arrays may be freed after the bind. */
+#define HPF_HELDOUT_SLOTS 4
+int  hpf_heldout_bind(hpf_handle *h, int slot, const uint32_t *u, const uint32_t *i, const int32_t *y, size_t cnt);
+int  hpf_heldout_ll_bound(hpf_handle *h, int slot, double *sum_out, uint64_t *cnt_out);
 
 /* replaces: HGAPRec::logl (hgaprec.cc:2160-2255), the bound written to
  * logl.txt with -logl: the per-nonzero term over this handle's nonzeros plus
@@ -328,7 +339,10 @@ typedef struct {
   uint32_t phi_G, phi_R, phi_V;      /* lanes per nonzero, loads per lane, doubles per load */
   uint32_t sweep_G, sweep_R;         /* row sweep: lanes per row, columns per lane */
   uint32_t ld;                       /* row stride of the device matrices, doubles */
-  uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph */
+  uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph; 2 (v8): a rank of several replays the */
+                                     /* iteration as three graphs cut by its collectives (hpf_iterate_local_items,        */
+                                     /* hpf_iterate_local_users, hpf_iterate_global; hpf_timing then holds the item half   */
+                                     /* under phi_item_ms, the user half under phi_user_ms, combine_* / sweep_user_ms 0)   */
   uint32_t w_layout;                 /* rows of W: 0 plain (phi_V elements per load), 3 packed 59-bit (lossless),  */
                                      /* 2 packed 48-bit (w_storage = 2), 4 plain doubles in the packed shape's     */
                                      /* 16-byte pieces (w_storage = 3, or after a fallback); 2-4: phi_R = pieces per lane */
@@ -347,8 +361,13 @@ typedef struct {
                                      /* this rank's PART there and a caller that owns the exchange has to sum-all-reduce  */
                                      /* it.  0 after hpf_snapshot_load of a state saved between iterations: the tail came */
                                      /* with the snapshot, already reduced; reducing it again would multiply it by the    */
-                                     /* number of ranks.  Read it BEFORE calling hpf_start_sums.                          */
-  uint32_t reserved0;
+                                     /* number of ranks.  v8: stays 1 after hpf_start_sums (no hpf_comm_init) until the   */
+                                     /* next iteration begins -- read it before or after that call.                       */
+  /* ABI v8 */
+  uint32_t tile_chunk_user;          /* segments per workgroup of that side's tiled pass (0: row-major): two per wave     */
+  uint32_t tile_chunk_item;          /* unless the list is too long for one launch of such chunks                         */
+  uint32_t phi_build;                /* build of the packed pass kernels in use: bits 0-3 waves per SIMD the registers are */
+                                     /* held to, bit 4 the owner's factors in LDS, bit 5 rows read by half their lanes     */
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 

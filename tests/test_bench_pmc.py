@@ -48,7 +48,7 @@ def test_lean_is_what_the_profiled_child_runs():
     """`--lean` must switch every side block off: the child that rocprofv3 profiles may not spawn rocprofv3 itself"""
     src = (ROOT / "bench.py").read_text()
     assert "args.no_pmc = args.no_other_configs = args.no_cpu_baseline = True" in src
-    assert '"--lean", "--steps", "3", "--warmup", "1"' in src
+    assert '"--lean", "--steps", str(steps), "--warmup", "1"' in src
 
 
 def test_inner_profiler_runs_do_not_inherit_an_outer_one():

@@ -326,6 +326,50 @@ def test_graph_replay_equals_eager_launches(orc, monkeypatch, bias):
     assert tms[0]["iterations"] == tms[1]["iterations"] == 6
 
 
+@pytest.mark.parametrize("hier,bias,novb", [(True, True, False), (True, False, False), (False, True, True)])
+def test_a_rank_of_several_replays_its_three_pieces_bit_identically(orc, monkeypatch, hier, bias, novb):
+    """Round 6: with n_ranks > 1 the iteration is cut by its collectives, so it is captured as THREE graphs -- item pass | user
+    pass + user sweep | item sweep -- replayed by hpf_iterate_local_items / _users / hpf_iterate_global.  Same kernels in the
+    same order: the bits of the eager pieces, through a get/set in between (graphs dropped and captured again), with the -novb
+    copy of the old column sums inside the user piece, and through hpf_iterate on a (one-rank) communicator of the library's."""
+    from hgaprec_amd.capi import Hpf
+    n, m, K = 400, 300, 20
+    rowptr, col, val = make_problem(n, m, 9000, 4)
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+    outs, infos = [], []
+    for mode, comm in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("HPF_GRAPH", mode)
+        M = orc.Model(n, m, K, hier, bias, False)
+        M.set_csr(rowptr, col, val); M.initialize(4)
+        D = Hpf(n, m, K, hier=hier, bias=bias, novb=novb, n_ranks=1 if comm else 2, rank=0, n_users_total=n)
+        D.upload_csr(rowptr, col, val)
+        copy_state(M, D, hier, bias)
+        if comm:
+            D.comm_init(Hpf.comm_unique_id())
+        elif novb:
+            D.start_sums()                          # one "rank" of two holding every user: its part IS the sum
+
+        def it(k):
+            if comm:
+                D.iterate(k)
+                return
+            for _ in range(k):
+                D.iterate_local_items(); D.iterate_local_users(); D.iterate_global()
+        it(2)
+        mid = D.get_state("BETA_E")                 # a synchronising export between replays
+        it(2)
+        D.iterate_local_phi(); D.iterate_local_sweep(); D.iterate_global()      # the other cut stays eager, in any mode
+        it(1)
+        infos.append((D.work_info()["graph_replay"], D.mean_timing(1)))
+        outs.append([D.get_state(w) for w in ("THETA_E", "BETA_E", "THETA_SHAPE", "BETA_SHAPE")] + [mid])
+        D.close()
+    for a, b, c in zip(*outs):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert [i[0] for i in infos] == [0, 2, 2]
+    assert infos[0][1]["sweep_user_ms"] > 0 and infos[1][1]["sweep_user_ms"] == 0 and infos[1][1]["phi_user_ms"] > 0
+    assert infos[1][1]["phi_item_ms"] > 0 and infos[1][1]["sweep_item_ms"] > 0 and infos[1][1]["iteration_ms"] > 0
+
+
 @pytest.mark.parametrize("hier,bias", [(True, True), (False, False)])
 def test_snapshot_restore_continues_bit_identically(orc, hier, bias):
     # hpf_snapshot_save / _load: the loop's device arrays verbatim.  A second handle that
@@ -701,6 +745,41 @@ def test_every_packed_kernel_shape_matches_the_oracle(orc, monkeypatch, K, ws):
         assert e < RTOL, (wi["phi_G"], wi["phi_R"], wi["sweep_G"], wi["sweep_R"], w, e)
 
 
+@pytest.mark.parametrize("waves,own_lds,x2", [(3, 0, 0), (4, 0, 0), (4, 1, 0), (3, 1, 0), (3, 0, 1), (3, 1, 1)],
+                         ids=["w3", "w4", "w4_lds", "w3_lds", "x2", "x2_lds"])
+@pytest.mark.parametrize("K,bias", [(50, False), (100, False), (100, True), (200, True)])
+def test_every_build_of_the_packed_pass_matches_the_oracle(orc, monkeypatch, K, bias, waves, own_lds, x2):
+    """Round 6: the builds of the packed pass for the shapes of six pieces per lane (K = 50, 100, 200) -- registers held to
+    three or four waves per SIMD, the owner's factors in registers or in LDS, rows read by all their lanes or by half of them
+    (codec_p59x2: a batch of twice the nonzeros) -- over long rows, empty rows and rows cut into several segments, against
+    the oracle; a build that keeps the lanes per nonzero sums in the same order as the default one: the same bits."""
+    from hgaprec_amd.capi import Hpf
+    n, m = 260, 170
+    kw = dict(prob_kw=dict(heavy_user=True, heavy_item=True, singles=True))
+    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
+    monkeypatch.setenv("HPF_PHI_WAVES", str(waves))
+    monkeypatch.setenv("HPF_PHI_OWN_LDS", str(own_lds))
+    monkeypatch.setenv("HPF_PHI_X2", str(x2))
+    monkeypatch.setenv("HPF_SEG_MAX", "64")            # rows of several segments, partial slots
+    M, D = _run_pair(orc, n, m, K, 9000, True, bias, False, 3, seed=3 + K, **kw)
+    wi = D.work_info()
+    halves = x2 and wi["phi_G"] >= 8
+    assert wi["w_layout"] == 3 and wi["phi_R"] == 6
+    assert wi["phi_build"] == ((2 if halves else waves) | (16 if own_lds else 0) | (32 if halves else 0)), wi
+    M.iterate(3); D.iterate(3)
+    for w in compare_states(True, bias):
+        e = rel_err(D.get_state(w), M.state(w))
+        assert e < RTOL, (wi["phi_G"], wi["phi_build"], w, e)
+    if not halves:
+        monkeypatch.delenv("HPF_PHI_WAVES"); monkeypatch.delenv("HPF_PHI_OWN_LDS"); monkeypatch.delenv("HPF_PHI_X2")
+        Mb, Db = _run_pair(orc, n, m, K, 9000, True, bias, False, 3, seed=3 + K, **kw)     # same lists (HPF_SEG_MAX), the default build
+        Db.iterate(3)
+        for w in compare_states(True, bias):
+            assert np.array_equal(D.get_state(w), Db.get_state(w)), (wi["phi_build"], w)
+        Db.close()
+    D.close()
+
+
 @pytest.mark.parametrize("K,bias", [(100, False), (50, True), (202, False)])
 def test_packed_rows_are_lossless_against_plain_rows(orc, monkeypatch, K, bias):
     """The 59-bit packing drops only bits that carry nothing: a packed run and a run with the same
@@ -915,3 +994,33 @@ def test_softmax_underflow_is_reported_not_hidden(orc):
         else:
             D.synchronize()
             assert np.all(np.isfinite(D.get_state("THETA_E")))
+
+
+def test_bound_heldout_sets_give_the_sum_of_the_unbound_call_bit_for_bit(orc):
+    """hpf_heldout_bind / hpf_heldout_ll_bound (ABI v8): a set validated and uploaded once gives, at every later state, the
+    very sum hpf_heldout_ll gives for the same pairs; slots are independent; an index out of range is refused at the bind
+    and leaves the slot as it was; an unbound slot says so; binding again replaces the set; an empty set sums to 0."""
+    from hgaprec_amd.capi import HpfError
+    M, D = _run_pair(orc, 300, 200, 20, 6000, True, True, False, 2, seed=4)
+    hu, hi, hy = heldout_pairs(300, 200, 700, seed=5)
+    hu2, hi2, hy2 = heldout_pairs(300, 200, 90, seed=6)
+    D.heldout_bind(0, hu, hi, hy)
+    D.heldout_bind(1, hu2, hi2, hy2)
+    for it in range(3):
+        assert D.heldout_ll_bound(0) == D.heldout_ll(hu, hi, hy)
+        assert D.heldout_ll_bound(1) == D.heldout_ll(hu2, hi2, hy2)
+        M.iterate(1); D.iterate(1)
+    assert abs(D.heldout_ll_bound(0)[0] - M.heldout_sum(hu, hi, hy)) / hu.size < 1e-9
+    with pytest.raises(HpfError):
+        D.heldout_ll_bound(2)
+    bad = hu.copy(); bad[3] = 300
+    with pytest.raises(HpfError):
+        D.heldout_bind(0, bad, hi, hy)
+    assert D.heldout_ll_bound(0) == D.heldout_ll(hu, hi, hy)          # the refused bind left the slot alone
+    D.heldout_bind(0, hu2, hi2, hy2)
+    assert D.heldout_ll_bound(0) == D.heldout_ll_bound(1)
+    D.heldout_bind(3, hu[:0], hi[:0], hy[:0])
+    assert D.heldout_ll_bound(3) == (0.0, 0)
+    with pytest.raises(HpfError):
+        D.heldout_bind(4, hu, hi, hy)
+    D.close()
