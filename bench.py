@@ -740,6 +740,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         replica_check = "ok" if bool(torch.equal(hi, lo)) and bool(torch.isfinite(hi).all()) else "MISMATCH"
+        beta_checksum = [float(cs[0]), float(cs[1])]                  # sum and max of BETA_E after the last iteration (comparing runs)
         del be
 
     rccl = None
@@ -905,6 +906,7 @@ def main():
                                         "heavy_min_nnz_user", "heavy_min_nnz_item", "w_fallbacks", "notes")},
             "handover": handover,
             "replica_check": replica_check, "self_check": self_check,
+            "beta_e_checksum": beta_checksum if use_dist else None,
             # (B_phi + B_rows of SURVEY.md 8d) / step time.  NOT an HBM figure: the user
             # pass's share is served by caches, so this can sit above what HBM delivers.
             "iteration_cache_inclusive_algorithmic_GBps":

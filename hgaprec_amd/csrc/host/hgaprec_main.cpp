@@ -214,6 +214,9 @@ struct Driver {
     // this rank's contiguous user range, balanced on the nnz prefix sum
     const auto parts = partition_users(rt.rowptr, comm.world);
     lo = parts[comm.rank].first; hi = parts[comm.rank].second;
+    if (comm.world > 1)
+      fprintf(stderr, "[rank %d] users [%u, %u) of %u: %lld of %lld ratings\n", comm.rank, lo, hi, n,
+              (long long)(rt.rowptr[hi] - rt.rowptr[lo]), (long long)rt.rowptr[n]);
     slice(rt.validation, lo, hi, &lvalid);
     slice(rt.test, lo, hi, &ltest);
 

@@ -175,6 +175,7 @@ struct hpf_handle {
   // page-locked buffer the DMA writes directly
   struct HeldSet { uint32_t *du = nullptr, *di = nullptr; int32_t *dy = nullptr; double *dout = nullptr, *hout = nullptr; size_t cnt = 0; bool bound = false; };
   HeldSet held[HPF_HELDOUT_SLOTS];
+  hipEvent_t held_ev[8] = {};
   std::string err;
 };
 
@@ -1473,8 +1474,12 @@ int build_split_graphs(hpf_handle *h)
   }
   return HPF_OK;
 }
-// a rank of several replays its pieces under the rule of the one-rank iteration: launch-bound problems (or HPF_GRAPH=1)
-bool split_graph_on(const hpf_handle *h) { return !h->in_recovery && want_graph(h); }
+// OPT-IN (HPF_GRAPH=1 under HPF_EXPERIMENTAL), never chosen by the library: measured on MI355X (profiles/r06/experiments.md 4)
+// the three replays buy nothing where the pieces are long -- an eighth of C4, 2.50 ms eager against 2.51 -- and LOSE where they
+// are short -- C1 through the pieces: 0.101 ms eager, 0.127 replayed: a replay costs the host 10-16 us, three of them more than
+// the eleven eager launches they stand for, which the host issues ahead of the device anyway.  (One graph for a whole
+// iteration -- one rank -- does pay: 0.085 ms.)
+bool split_graph_on(const hpf_handle *h) { return !h->in_recovery && h->graph_mode == 1; }
 
 // allow_graph: the caller goes on with hpf_iterate_local_users and hpf_iterate_global -- the cut the graphs are captured along
 int phi_items(hpf_handle *h, bool allow_graph = false)
@@ -1969,6 +1974,7 @@ void hpf_destroy(hpf_handle *h)
   if (!h->exch_external) dfree(h->exch);
   dfree(h->logfact); dfree(h->rowptr_dev); dfree(h->colptr_dev); dfree(h->flags); dfree(h->u_colsum_prev);
   for (int k = 0; k < HPF_HELDOUT_SLOTS; ++k) free_held(h->held[k]);
+  for (int k = 0; k < 8; ++k) if (h->held_ev[k]) (void)hipEventDestroy(h->held_ev[k]);
   for (int k = 0; k < 2; ++k) {
     if (h->stage[k]) (void)hipHostFree(h->stage[k]);
     if (h->stage_ev[k]) (void)hipEventDestroy(h->stage_ev[k]);
@@ -2574,7 +2580,7 @@ namespace {
 // per-pair log-likelihoods of cnt pairs whose indices lie on the device, into hout (host; page-locked for a bound set),
 // summed serially in the order handed in: the map order of hgaprec.cc:1455-1465
 int heldout_run(hpf_handle *h, const uint32_t *du, const uint32_t *di, const int32_t *dy, double *dout, double *hout, size_t cnt,
-                double *sum_out)
+                double *sum_out, bool pinned)
 {
   int rc;
   if ((rc = check_flags(h))) return rc;
@@ -2588,7 +2594,32 @@ int heldout_run(hpf_handle *h, const uint32_t *du, const uint32_t *di, const int
   const uint32_t blocks = (uint32_t)std::min<size_t>((cnt + 15) / 16, 4096);
   hipLaunchKernelGGL(heldout_ll_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
   if ((rc = check_launch(h, "heldout_ll"))) return rc;
-  hipError_t e = hipMemcpyAsync(hout, dout, cnt * 8, hipMemcpyDeviceToHost, h->stream);
+  // The sum is a chain of dependent adds in the order handed in -- that order is the contract -- and at 10^6 pairs it is what the
+  // call costs (~0.8 ns per pair).  Into page-locked memory the values therefore arrive in pieces, and the host adds piece c
+  // while piece c + 1 is on the wire: the DMA disappears behind the chain.  (Pageable memory: one copy, as before.)
+  constexpr int PIECES = 8;
+  const bool piped = pinned && cnt >= ((size_t)1 << 16);
+  hipError_t e = hipSuccess;
+  if (piped) {
+    for (int c = 0; c < PIECES && e == hipSuccess; ++c)
+      if (!h->held_ev[c]) e = hipEventCreateWithFlags(&h->held_ev[c], hipEventDisableTiming);
+    const size_t per = (cnt + PIECES - 1) / PIECES;
+    for (int c = 0; c < PIECES && e == hipSuccess; ++c) {
+      const size_t p0 = std::min(cnt, (size_t)c * per), p1 = std::min(cnt, p0 + per);
+      if (p1 > p0) e = hipMemcpyAsync(hout + p0, dout + p0, (p1 - p0) * 8, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipEventRecord(h->held_ev[c], h->stream);
+    }
+    double s = .0;
+    for (int c = 0; c < PIECES && e == hipSuccess; ++c) {
+      e = hipEventSynchronize(h->held_ev[c]);
+      const size_t p0 = std::min(cnt, (size_t)c * per), p1 = std::min(cnt, p0 + per);
+      for (size_t p = p0; p < p1; ++p) s += hout[p];
+    }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->stream); h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
+    *sum_out = s;
+    return HPF_OK;
+  }
+  e = hipMemcpyAsync(hout, dout, cnt * 8, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return HPF_ERR_HIP; }
   double s = .0;
@@ -2618,7 +2649,7 @@ int hpf_heldout_ll(hpf_handle *h, const uint32_t *u, const uint32_t *i, const in
     if (e == hipSuccess) e = hipMemcpyAsync(di, i, cnt * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dy, y, cnt * 4, hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = HPF_ERR_HIP; break; }
-    rc = heldout_run(h, du, di, dy, dout, out.data(), cnt, sum_out);
+    rc = heldout_run(h, du, di, dy, dout, out.data(), cnt, sum_out, false);
   } while (0);
   dfree(du); dfree(di); dfree(dy); dfree(dout);
   return rc;
@@ -2653,7 +2684,7 @@ int hpf_heldout_ll_bound(hpf_handle *h, int slot, double *sum_out, uint64_t *cnt
   *sum_out = 0.0; if (cnt_out) *cnt_out = hs.cnt;
   if (hs.cnt == 0) return HPF_OK;
   if (!(h->u.have_E && h->it.have_E) && h->iterations == 0) { h->err = "E state not set"; return HPF_ERR_STATE; }
-  return heldout_run(h, hs.du, hs.di, hs.dy, hs.dout, hs.hout, hs.cnt, sum_out);
+  return heldout_run(h, hs.du, hs.di, hs.dy, hs.dout, hs.hout, hs.cnt, sum_out, true);
 }
 
 int hpf_elbo(hpf_handle *h, double *out)
@@ -2885,7 +2916,7 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->w_fallbacks = h->fallbacks;
   out->notes = h->notes;
   out->start_sums_pending = (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done || h->tail_partial)) ? 1u : 0u;
-  out->graph_replay = (h->have_csr && want_graph(h)) ? ((h->cfg.n_ranks == 1 && !h->comm) ? 1u : 2u) : 0u;
+  out->graph_replay = (h->cfg.n_ranks == 1 && !h->comm) ? ((h->have_csr && want_graph(h)) ? 1u : 0u) : (h->have_csr && split_graph_on(h) ? 2u : 0u);
   out->tile_chunk_user = h->u.chunks ? h->u.chunk_segs : 0; out->tile_chunk_item = h->it.chunks ? h->it.chunk_segs : 0;
   {
     const bool six = h->wl == WL_P59 && h->phiR == 6;                 // the shapes the other builds exist for (launch_phipk_t)

@@ -209,8 +209,9 @@ int  hpf_snapshot_load(hpf_handle *h, const void *host, size_t bytes);
  * replay one captured iteration as a hipGraph: same kernels in the same
  * order, identical bits; such iterations report only iteration_ms in
  * hpf_timing (the per-kernel fields read 0).  With n_ranks > 1 (or a communicator)
- * the same rule replays the iteration as THREE graphs -- item pass | user pass + user
- * sweep | item sweep -- around the two collectives (v8; hpf_work_info.graph_replay = 2). */
+ * the iteration is cut by its collectives; HPF_GRAPH=1 (experimental, opt-in: measured, it does
+ * not pay) replays it as THREE graphs -- item pass | user pass + user sweep | item sweep --
+ * (v8; hpf_work_info.graph_replay = 2). */
 int  hpf_iterate(hpf_handle *h, int n_iters);
 
 /* n_ranks > 1: step A for the local users, the local user sweep (B, D-user,
@@ -339,7 +340,7 @@ typedef struct {
   uint32_t phi_G, phi_R, phi_V;      /* lanes per nonzero, loads per lane, doubles per load */
   uint32_t sweep_G, sweep_R;         /* row sweep: lanes per row, columns per lane */
   uint32_t ld;                       /* row stride of the device matrices, doubles */
-  uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph; 2 (v8): a rank of several replays the */
+  uint32_t graph_replay;             /* 1: hpf_iterate replays a captured hipGraph; 2 (v8, opt-in): a rank of several replays the */
                                      /* iteration as three graphs cut by its collectives (hpf_iterate_local_items,        */
                                      /* hpf_iterate_local_users, hpf_iterate_global; hpf_timing then holds the item half   */
                                      /* under phi_item_ms, the user half under phi_user_ms, combine_* / sweep_user_ms 0)   */

@@ -572,3 +572,63 @@ def test_cli_matches_reference_fixtures(tmp_path, case):
                     assert x == y, name
                     continue
                 assert abs(xv - yv) <= 1e-4 * abs(yv) + 2.1e-8, (name, a, b)
+
+
+def test_eight_process_cli_with_a_one_user_rank_equals_the_one_process_run(tmp_path):
+    """`hgaprec -ngpus 8 -comm host` (eight real processes on GPU 0) on a C4-shaped job -- `-hier -bias`,
+    capacities -n 3000 -m 200 -- whose nnz-balanced cut leaves one rank a SINGLE user (a user holding an eighth of the
+    ratings, sitting on a cut): the output directory must be the one-process run's under the comparison rule of SURVEY.md
+    8(c) (factors 1e-4 |b| + 5e-9, LL series 1e-6, integer columns exact), and no part file may outlive the run."""
+    import re
+    rng = np.random.default_rng(3)
+    m, singles, heavy_at = 200, 800, 375
+    data = tmp_path / "data"
+    data.mkdir()
+    uid = rng.permutation(50000)[: singles + 1] + 1
+    iid = rng.permutation(5000)[:m] + 1
+    with open(data / "train.tsv", "w") as ft, open(data / "validation.tsv", "w") as fv, open(data / "test.tsv", "w") as fs:
+        seq = 0
+        for k in range(singles + 1):
+            if k == heavy_at:                              # seq 375: 200 ratings = an eighth of the 1000 training ratings
+                for i in rng.permutation(m):
+                    ft.write(f"{uid[k]}\t{iid[i]}\t{1 + int(rng.integers(5))}\n")
+                continue
+            a, b = rng.choice(m, 2, replace=False)
+            ft.write(f"{uid[k]}\t{iid[a]}\t{1 + int(rng.integers(5))}\n")
+            (fv if k % 3 == 0 else fs).write(f"{uid[k]}\t{iid[b]}\t{1 + int(rng.integers(5))}\n")
+            seq += 1
+    args = ["-dir", str(data), "-n", "3000", "-m", "200", "-k", "8", "-hier", "-bias", "-seed", "5", "-rfreq", "3", "-max-iterations", "9"]
+    outs = {}
+    for world in (1, 8):
+        wd = tmp_path / f"w{world}"
+        wd.mkdir()
+        r = subprocess.run([str(EXE)] + args + (["-ngpus", "8", "-device", "0", "-comm", "host"] if world > 1 else []), cwd=wd,
+                           capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+        ds = [p for p in wd.iterdir() if p.is_dir() and p.name.startswith("n3000-m200-k8")]
+        assert len(ds) == 1
+        outs[world] = ds[0]
+        if world == 8:
+            ranges = {int(x[0]): (int(x[1]), int(x[2]), int(x[3])) for x in
+                      re.findall(r"\[rank (\d)\] users \[(\d+), (\d+)\) of \d+: (\d+) of \d+ ratings", r.stderr)}
+            assert sorted(ranges) == list(range(8)), r.stderr[-2000:]
+            assert any(b - a == 1 for a, b, _ in ranges.values()), ranges               # the rank with one user
+            assert sum(z for _, _, z in ranges.values()) == 1000 and ranges[0][0] == 0 and ranges[7][1] == singles + 1
+            assert all(ranges[k][1] == ranges[k + 1][0] for k in range(7))
+            leftovers = [p.name for p in ds[0].iterdir() if ".part" in p.name or p.name.endswith(".writing")]
+            assert not leftovers, leftovers
+    one, eight = outs[1], outs[8]
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in eight.iterdir())
+    for f in ("validation.txt", "test.txt"):
+        a, b = series(eight / f), series(one / f)
+        assert [x[0] for x in a] == [x[0] for x in b] and [x[2] for x in a] == [x[2] for x in b]
+        assert max(abs(x[1] - y[1]) for x, y in zip(a, b)) <= 1e-6
+    for f in ("byusers.tsv", "byitems.tsv", "precision.txt"):
+        assert (eight / f).read_text() == (one / f).read_text(), f
+    for nm in ("hbeta", "htheta", "betarate", "thetarate", "betabias", "thetabias"):
+        for suf in ("", "_shape", "_rate"):
+            ia, va = read_tsv(eight / f"{nm}{suf}.tsv")
+            ib, vb = read_tsv(one / f"{nm}{suf}.tsv")
+            assert np.array_equal(ia, ib), nm + suf
+            assert np.all(np.abs(va - vb) <= 1e-4 * np.abs(vb) + 5e-9), nm + suf

@@ -365,3 +365,82 @@ def test_one_gpu_bench_takes_the_distributed_path():
     # a real (one-rank) RCCL communicator: its version and what its own log said
     assert d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["version"]
     assert d["rccl"]["log"].get("lines", 0) > 0, d["rccl"]
+
+
+def test_eight_ranks_through_the_launcher_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` with every rank on GPU 0 (gloo carries the
+    all-reduce): the launcher, the cut of ONE matrix into eight nnz-balanced user ranges each rank generates on its own, the
+    partition hand-over, both exchange orders side by side and rank 0's PMC child over rank 0's own range -- the pieces of the
+    first 8-GPU run that one GPU can exercise (VERDICT r5 #4).  C3 cut to 0.5 %."""
+    import torch
+    from hgaprec_amd import synth
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+                        "--gpus", "8", "--steps", "3", "--warmup", "1", "--scale", "0.005",
+                        "--backend", "gloo", "--same-device"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["replica_check"] == "ok" and d["self_check"]["ok"]
+    cfg = synth.CONFIGS["C3"]
+    n, m, nnz = int(cfg["n"] * 0.005), int(cfg["m"] * 0.005), int(cfg["nnz"] * 0.005)
+    rp, _, _ = synth.generate_device(n, m, nnz, cfg["alpha_u"], cfg["alpha_i"], seed=cfg["seed"], device=torch.device("cuda", 0))
+    pr = d["per_rank"]
+    assert len(pr) == 8 and [x["rank"] for x in pr] == list(range(8))
+    assert sum(x["nnz"] for x in pr) == int(rp[-1]) == d["config"]["nnz_total"] and sum(x["users"] for x in pr) == n
+    assert max(x["nnz"] for x in pr) < 1.05 * int(rp[-1]) / 8
+    assert all(x["phi_item_ms"] > 0 and x["exchange_wait_ms"] >= 0 for x in pr)
+    # both exchange orders, timed in the same run
+    am = d["allreduce_modes_ms"]
+    assert am["pair_overlapped"]["ms_per_step"] > 0 and am["single_fused"]["ms_per_step"] > 0 and am["timed_region_used"] == "pair_overlapped"
+    assert d["rccl"]["world_size"] == 8 and d["rccl"]["backend"] == "gloo" and d["rccl"]["path"] == "torch"
+    # the line stands on the N = 1 rules: rank 0's child profiled rank 0's own range
+    rf = d["roofline"]
+    assert rf["frac_basis"].startswith("memory-side") and rf["traffic"] and 0 < rf["frac"] <= 1.0, rf
+    assert f"--user-range 0 {pr[0]['users']}" in rf["traffic_source"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    sp = d["speedup_vs_1gpu_same_workload"]
+    assert sp["source"].startswith("same run") and sp["one_gpu_nnz"] == int(rp[-1])
+
+
+def test_one_gpu_bench_library_comm_path():
+    """bench.py --comm library on one rank (HPF_BENCH_FORCE_DIST=1): the timed loop is hpf_comm_init + hpf_iterate -- the
+    library's own dlopen'ed RCCL calls on its communication stream, what `hgaprec -ngpus N -comm rccl` runs -- on a real
+    one-rank communicator; the line says which path it timed and carries the fields of the torch path."""
+    outs = {}
+    for comm in ("torch", "library"):
+        env = dict(os.environ, HPF_BENCH_FORCE_DIST="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.01",
+                            "--no-cpu-baseline", "--no-pmc", "--comm", comm],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[comm] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for comm, d in outs.items():
+        assert d["rccl"]["path"] == comm and d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1
+        assert d["replica_check"] == "ok" and d["self_check"]["ok"] and len(d["per_rank"]) == 1
+        assert d["exposed_allreduce_ms"]["max"] >= 0 and set(d["allreduce_modes_ms"]) >= {"pair_overlapped", "single_fused"}
+    assert set(outs["torch"]) == set(outs["library"])                 # the same fields either way
+
+
+def test_two_gpus_bench_library_comm_equals_torch_comm():
+    """two GPUs: `bench.py --gpus 2 --comm library` and `--comm torch` end in the same BETA_E (checksums in the line agree to
+    1e-12) -- the same kernels around the same sums, whoever issues the collective"""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    sums = {}
+    for comm in ("torch", "library"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+                            "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "0.01", "--no-cpu-baseline", "--no-pmc",
+                            "--no-1gpu-reference", "--comm", comm],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["rccl"]["path"] == comm and d["replica_check"] == "ok"
+        sums[comm] = d["beta_e_checksum"]
+    assert abs(sums["torch"][0] - sums["library"][0]) <= 1e-12 * abs(sums["torch"][0])
+    assert abs(sums["torch"][1] - sums["library"][1]) <= 1e-12 * abs(sums["torch"][1])

@@ -366,7 +366,8 @@ def test_a_rank_of_several_replays_its_three_pieces_bit_identically(orc, monkeyp
     for a, b, c in zip(*outs):
         assert np.array_equal(a, b) and np.array_equal(a, c)
     assert [i[0] for i in infos] == [0, 2, 2]
-    assert infos[0][1]["sweep_user_ms"] > 0 and infos[1][1]["sweep_user_ms"] == 0 and infos[1][1]["phi_user_ms"] > 0
+    # replayed pieces: the events inside a piece coincide (a few microseconds apart), the piece's time sits in its first field
+    assert infos[0][1]["sweep_user_ms"] > 0 and infos[1][1]["sweep_user_ms"] < 0.02 and infos[1][1]["phi_user_ms"] > 0
     assert infos[1][1]["phi_item_ms"] > 0 and infos[1][1]["sweep_item_ms"] > 0 and infos[1][1]["iteration_ms"] > 0
 
 
