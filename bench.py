@@ -139,19 +139,43 @@ def clean_profiler_env(env):
     return out
 
 
-L2_GATHER_CEILING_GBS = 31000.0   # random whole-row gathers served by the XCDs' L2s (tools/gather_ceiling.hip: 31-32 TB/s out of 3.6 MB,
-                                   # profiles/r03/gather_ceiling.json, r05 the same); the L2's own peak in the guide: 34.5 TB/s
+# What the machine gives whole-row gathers (tools/mixed_gather.hip, profiles/r06/mixed_gather.json; tools/gather_ceiling.hip before it):
+# 33 TB/s when every row is in the XCD's own L2, 7.1 TB/s when every row comes over the fabric (Infinity Cache or HBM alike) -- and
+# for a stream of which a share f hits, NOT the faster of the two side by side but their serial sum, 1 / (f / 33 + (1 - f) / 7.1)
+# (measured: at f = 0.73 15.0 TB/s, the serial model 16.2, side by side would be 26): hits and misses go through one pipeline.
+L2_GATHER_CEILING_GBS = 33000.0
+FABRIC_GATHER_CEILING_GBS = 7100.0
 
 
-def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0, extra=(), steps=3):
+def mixed_stream_ceiling(hit):
+    """GB/s the memory system gives row gathers of which a share `hit` is served by the XCD's L2 (serial model above)"""
+    hit = min(max(hit, 0.0), 1.0)
+    return 1.0 / (hit / L2_GATHER_CEILING_GBS + (1.0 - hit) / FABRIC_GATHER_CEILING_GBS)
+
+
+def l2_side(per_sd, ms):
+    """L2-side figures of one pass from its per-launch counters: hit rate, requests x 128 B / time, and that against the
+    mixed-stream ceiling for this hit rate.  {} without the counters."""
+    if not per_sd or "TCC_REQ_sum" not in per_sd or ms <= 0:
+        return {}
+    hit, miss = per_sd.get("TCC_HIT_sum", 0.0), per_sd.get("TCC_MISS_sum", 0.0)
+    if hit + miss <= 0:
+        return {}
+    e = {"l2_hit_rate": hit / (hit + miss), "l2_side_GBps": per_sd["TCC_REQ_sum"] * 128.0 / (ms * 1e-3) / 1e9}
+    e["mixed_stream_ceiling_GBps"] = mixed_stream_ceiling(e["l2_hit_rate"])
+    e["frac_of_mixed_stream_ceiling"] = e["l2_side_GBps"] / e["mixed_stream_ceiling_GBps"]
+    return e
+
+
+def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0, steps=3):
     """HBM-side traffic of the phi passes, measured IN THIS RUN: two `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X guide section "rocprofv3 PMC
     slots") over `bench.py --lean --steps 3 --warmup 1` of the same workload, spawned after the
     timed region while this process is idle.  Per launch: bytes = 2 x FETCH_SIZE x 1024 / cal +
     WRITE_SIZE x 1024, the x 2 being the guide's gfx950 correction and `cal` its calibration in the
     same pass on materialize_es_kernel, which reads n_rows_big x ld doubles by construction.
-    `extra`: further counter groups, one more pass each (e.g. ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")): their per-launch
-    averages land beside FETCH_SIZE / WRITE_SIZE; a failing extra pass is noted in per["extra_error"], not fatal.
+    The L2's own counters ride along (round 6: the TCC block's four slots take FETCH_SIZE + TCC_HIT_sum in one pass and
+    WRITE_SIZE + TCC_REQ_sum + TCC_MISS_sum in the other, checked on gfx950); a pass that refuses the group is repeated bare.
     -> ({side: {"fetch_KiB", "write_KiB", "launches"}}, cal dict, note) or (None, None, why)"""
     import csv
     import glob
@@ -172,30 +196,24 @@ def pmc_passes(argv_workload, n_rows_big, ld, tmo=300, local_rank=0, extra=(), s
     cal = {}
     t0 = time.perf_counter()
     try:
-        for gi, group in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",)) + tuple(tuple(g) for g in extra)):
-            d = os.path.join(tmp, f"g{gi}")
-            cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, str(ROOT / "bench.py"), "--lean", "--steps", str(steps), "--warmup", "1"] + argv_workload
-            try:
+        for gi, group in enumerate((("FETCH_SIZE", "TCC_HIT_sum"), ("WRITE_SIZE", "TCC_REQ_sum", "TCC_MISS_sum"))):
+            for attempt in (group, group[:1]):
+                d = os.path.join(tmp, f"g{gi}_{len(attempt)}")
+                cmd = [exe, "--kernel-trace", "--pmc", *attempt, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                       sys.executable, str(ROOT / "bench.py"), "--lean", "--steps", str(steps), "--warmup", "1"] + argv_workload
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=tmo)
-            except subprocess.TimeoutExpired:
-                if gi >= 2:
-                    per["extra_error"] = f"pass {' '.join(group)} timed out"
-                    continue
-                raise
-            if r.returncode != 0:
-                if gi >= 2:
-                    per["extra_error"] = f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
-                    continue
-                return None, None, f"rocprofv3 --pmc {group[0]} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
-            for ctr in group:
+                if r.returncode == 0:
+                    break
+                if len(attempt) == 1:
+                    return None, None, f"rocprofv3 --pmc {attempt[0]} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            for ctr in attempt:
                 vals, calv = parse_counter_csvs(d, ctr)
                 for sd in (0, 1):
                     v = vals[sd][1:] if len(vals[sd]) > 1 else vals[sd]        # the first launch is the warm-up iteration
                     if v:
                         per[sd][ctr] = sum(v) / len(v)
                         per[sd]["launches"] = len(v)
-                if calv and gi < 2:
+                if calv and ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                     cal[ctr] = max(calv) * 1024.0                                # the larger side's launch
         if not all("FETCH_SIZE" in per[sd] and "WRITE_SIZE" in per[sd] for sd in (0, 1)):
             return None, None, "rocprofv3 ran but the phi kernels were not in its counter CSV"
@@ -377,17 +395,16 @@ def side_roofline(out, wl, n_big, local_rank, budget_s):
     if budget_s <= 5:
         return {"skipped": "the time budget of the per-shape counter passes is spent"}
     t0 = time.perf_counter()
-    per, cal, note = pmc_passes(wl, n_big, out["ld"], tmo=max(30, int(budget_s)), local_rank=local_rank,
-                                extra=(("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"),), steps=2)
+    per, cal, note = pmc_passes(wl, n_big, out["ld"], tmo=max(30, int(budget_s)), local_rank=local_rank, steps=2)
     if not per:
         return {"skipped": note, "seconds": round(time.perf_counter() - t0, 1)}
     fcal = cal.get("fetch_x2_over_known_read") or 1.0
     fcal = fcal if 0.9 < fcal < 1.25 else 1.0
     km, ab = out["kernels_ms"], out["algorithmic_bytes"]
     blk = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic_source": note, "fetch_calibration_applied": fcal,
-           "l2_gather_ceiling_GBps": L2_GATHER_CEILING_GBS, "seconds": None, "per_kernel": {}}
-    if per.get("extra_error"):
-        blk["l2_counters"] = per["extra_error"]
+           "gather_ceilings_GBps": {"all_hits": L2_GATHER_CEILING_GBS, "all_misses": FABRIC_GATHER_CEILING_GBS,
+                                    "model": "hit share f: 1 / (f / all_hits + (1 - f) / all_misses) -- tools/mixed_gather.hip"},
+           "seconds": None, "per_kernel": {}}
     for sd, nm in ((1, "phi_item"), (0, "phi_user")):
         ms = km.get(nm + "_ms") or 0.0
         if ms <= 0 or "FETCH_SIZE" not in per[sd]:
@@ -396,19 +413,18 @@ def side_roofline(out, wl, n_big, local_rank, budget_s):
         e = {"ms": round(ms, 4), "traffic": traffic, "achieved": traffic / (ms * 1e-3) / 1e9, "algorithmic_bytes": ab[nm],
              "algorithmic_GBps": ab[nm] / (ms * 1e-3) / 1e9, "traffic_over_algorithmic": traffic / ab[nm]}
         e["frac"] = e["achieved"] / HBM_PEAK_GBS
-        if "TCC_REQ_sum" in per[sd]:
-            hit, miss = per[sd].get("TCC_HIT_sum", 0.0), per[sd].get("TCC_MISS_sum", 0.0)
-            e["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
-            e["l2_side_GBps"] = per[sd]["TCC_REQ_sum"] * 128.0 / (ms * 1e-3) / 1e9
-            e["l2_side_frac"] = e["l2_side_GBps"] / L2_GATHER_CEILING_GBS
-            e["binding"] = ("l2" if e["l2_side_frac"] > e["frac"] else "hbm") if e["traffic_over_algorithmic"] < 0.5 else "hbm"
+        e.update(l2_side(per[sd], ms))
+        if "l2_hit_rate" in e:
+            # which ceiling the pass sits under: most of its rows crossing the fabric -> the HBM-side fraction; most of them served
+            # by the L2s -> the memory system's rate for a stream with this hit share
+            e["binding"] = "fabric (hbm-side frac)" if e["traffic_over_algorithmic"] >= 0.5 else "mixed L2 / fabric stream (frac_of_mixed_stream_ceiling)"
         blk["per_kernel"][nm] = e
     dom = max(blk["per_kernel"], key=lambda k: blk["per_kernel"][k]["ms"], default=None)
     if dom:
         d = blk["per_kernel"][dom]
         blk.update({"kernel": f"{dom} pass", "achieved": d["achieved"], "frac": d["frac"], "traffic": d["traffic"], "avg_launch_ms": d["ms"],
-                    "frac_basis": "memory-side traffic (PMC counters of this run) / launch time / peak; per_kernel.*.l2_side_frac where "
-                                  "the pass lives on its L2 hits (traffic_over_algorithmic < 0.5)"})
+                    "frac_basis": "memory-side traffic (PMC counters of this run) / launch time / peak; per_kernel.*."
+                                  "frac_of_mixed_stream_ceiling where the pass lives on its L2 hits (traffic_over_algorithmic < 0.5)"})
     blk["seconds"] = round(time.perf_counter() - t0, 1)
     return blk
 
@@ -1072,7 +1088,8 @@ def main():
                 for sd, nm in ((0, "phi_user"), (1, "phi_item")):
                     tr[nm] = int(2.0 * per[sd]["FETCH_SIZE"] * 1024.0 / fcal + per[sd]["WRITE_SIZE"] * 1024.0)
                 traffic = tr[kern]
-                pmc = {"per_launch_bytes": tr, "FETCH_SIZE_KiB": {"phi_user": per[0]["FETCH_SIZE"], "phi_item": per[1]["FETCH_SIZE"]},
+                l2s = {nm: l2_side(per[sd], tm[nm + "_ms"]) for sd, nm in ((0, "phi_user"), (1, "phi_item"))}
+                pmc = {"per_launch_bytes": tr, "l2_side": l2s, "FETCH_SIZE_KiB": {"phi_user": per[0]["FETCH_SIZE"], "phi_item": per[1]["FETCH_SIZE"]},
                        "WRITE_SIZE_KiB": {"phi_user": per[0]["WRITE_SIZE"], "phi_item": per[1]["WRITE_SIZE"]},
                        "launches_averaged": per[1].get("launches"), "calibration": cal, "fetch_calibration_applied": fcal,
                        "formula": "bytes = 2 x FETCH_SIZE x 1024 / fetch_calibration + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE counts 128-B "
@@ -1136,6 +1153,9 @@ def main():
             "hbm_only_source": hbm_only_note if hbm_only else None,
             "hbm_only_run": hbm_only_run,
             # the same pass with the arithmetic taken out: what the memory system needs for its gathers alone
+            # the L2's side of the dominant kernel (same counter passes): hit rate, requests x 128 B / time, and that against what the
+            # memory system gives a stream of row gathers with this hit share (mixed_stream_ceiling)
+            "l2_side": (pmc or {}).get("l2_side", {}).get(kern),
             "gather_only_ms": (gather_only or {}).get(kern),
             "frac_of_gather_only": (gather_only[kern] / kms) if gather_only and kern in gather_only and kms > 0 else None,
             "w_rows": {0: "plain fp64", 2: "48-bit (opt-in, lossy)", 3: "59-bit packed fp64 (lossless)",

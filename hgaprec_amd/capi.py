@@ -103,7 +103,7 @@ class HpfWorkInfo(C.Structure):
         ("heavy_min_nnz_user", C.c_uint64), ("heavy_min_nnz_item", C.c_uint64),
         ("w_fallbacks", C.c_uint32), ("notes", C.c_uint32),
         ("start_sums_pending", C.c_uint32), ("tile_chunk_user", C.c_uint32), ("tile_chunk_item", C.c_uint32),
-        ("phi_build", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

@@ -144,10 +144,7 @@ struct hpf_handle {
   // user pass, a C3 shard: unchanged).  Same segments, same order inside each: the same bits.  HPF_PHI_WG forces 64 | 128 | 256.
   uint32_t phi_wg = 0;
   uint32_t wg_of(bool tiled) const { return wl == WL_PLAIN ? 256u : phi_wg ? phi_wg : (tiled ? 64u : 256u); }   // (plain rows: phi_pass_kernel, always 256)
-  // build of the packed pass kernels (round 6; the p59 shapes of six pieces per lane): waves per SIMD the registers are held
-  // to, the owner's factors in LDS, rows read by half their lanes.  HPF_PHI_WAVES / HPF_PHI_OWN_LDS / HPF_PHI_X2 force them.
-  int phi_waves = 3, phi_own_lds = 0, phi_x2 = 0; uint32_t phi_lds_pad = 0;
-  uint32_t nz_per_batch() const { return phiG > 0 ? 64u / (uint32_t)(phi_x2 && wl == WL_P59 && phiG >= 8 && phiR == 6 ? phiG / 2 : phiG) : 8u; }
+  uint32_t nz_per_batch() const { return phiG > 0 ? 64u / (uint32_t)phiG : 8u; }
   static constexpr uint32_t RING = 64;          // timed iterations kept
   hipEvent_t evr[RING][8] = {};
   hipEvent_t *ev = evr[0];                      // events of the iteration in flight
@@ -408,39 +405,15 @@ bool launch_sweep(int mode, int G, int R, const SweepArgs &a, uint32_t blocks, h
 }
 
 // how a packed phi pass is launched: workgroups x threads (256 = four waves that share a chunk of segments, 64 = one wave: a
-// tiled side), and the build of the kernel -- waves per SIMD its registers are held to, the owner's factors in registers or
-// in LDS, rows read by all their lanes or by half of them (codec_p59x2)
-struct PhiLaunch { uint32_t blocks, wg; hipStream_t st; int waves, own_lds, x2; uint32_t lds_pad; };    // lds_pad: dynamic LDS bytes per wave, asked for
-                                                                                                         // and never touched -- caps the waves a CU holds (HPF_PHI_LDS_PAD: occupancy experiments)
-
-template <template <int> class C> struct is_p59 { static constexpr bool value = false; };
-template <> struct is_p59<codec_p59> { static constexpr bool value = true; };
+// tiled side) on a stream -- handed down explicitly (until round 5 the thread count travelled in a thread_local)
+struct PhiLaunch { uint32_t blocks, wg; hipStream_t st; };
 
 // packed W rows: G lanes per nonzero, L 16-byte pieces per lane (phi_pass_packed_kernel)
-template <template <int> class C, int G, int L, int WAVES, int OWN>
-void launch_phipk_v(int side, const PhiArgs &a, const PhiLaunch &pl)
-{
-  const size_t dyn = (size_t)pl.lds_pad * (pl.wg / 64);
-  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, WAVES, OWN, 1>), dim3(pl.blocks), dim3(pl.wg), dyn, pl.st, a);
-  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, WAVES, OWN, 0>), dim3(pl.blocks), dim3(pl.wg), dyn, pl.st, a);
-}
 template <template <int> class C, int G, int L>
 void launch_phipk_t(int side, const PhiArgs &a, const PhiLaunch &pl)
 {
-  // the other builds exist for the shapes of six pieces per lane -- K = 50, 100, 200: (4, 6), (8, 6), (16, 6) -- of the lossless rows
-  if constexpr (is_p59<C>::value && L == 6) {
-    if (pl.x2) {
-      if constexpr (G >= 8) {
-        if (pl.own_lds) launch_phipk_v<codec_p59x2, G / 2, 12, 2, 1>(side, a, pl);
-        else            launch_phipk_v<codec_p59x2, G / 2, 12, 2, 0>(side, a, pl);
-        return;
-      }
-    }
-    if (pl.waves == 4 && pl.own_lds) { launch_phipk_v<C, G, L, 4, 1>(side, a, pl); return; }
-    if (pl.waves == 4) { launch_phipk_v<C, G, L, 4, 0>(side, a, pl); return; }
-    if (pl.own_lds) { launch_phipk_v<C, G, L, 3, 1>(side, a, pl); return; }
-  }
-  launch_phipk_v<C, G, L, 3, 0>(side, a, pl);
+  if (side & 1) hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 1>), dim3(pl.blocks), dim3(pl.wg), 0, pl.st, a);
+  else          hipLaunchKernelGGL((phi_pass_packed_kernel<C, G, L, 0>), dim3(pl.blocks), dim3(pl.wg), 0, pl.st, a);
 }
 template <template <int> class C, int G>
 bool launch_phipk_l(int L, int side, const PhiArgs &a, const PhiLaunch &pl)
@@ -494,14 +467,12 @@ template <int G>
 bool launch_gather_only_l(int L, const PhiArgs &a, uint32_t *sink, const PhiLaunch &pl)
 {
 #define GO(LL) case LL: hipLaunchKernelGGL((gather_only_kernel<G, LL>), dim3(pl.blocks), dim3(pl.wg), 0, pl.st, a, sink); return true;
-  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) GO(12) }
+  switch (L) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) }
 #undef GO
   return false;
 }
-// (a row of G lanes x L pieces read by half its lanes IS a row of G/2 lanes x 2L pieces: codec_p59x2)
 bool launch_gather_only(int G, int L, const PhiArgs &a, uint32_t *sink, const PhiLaunch &pl)
 {
-  if (pl.x2 && G >= 8 && L == 6) { G /= 2; L *= 2; }
   switch (G) {
     case 4:  return launch_gather_only_l<4>(L, a, sink, pl);
     case 8:  return launch_gather_only_l<8>(L, a, sink, pl);
@@ -1384,7 +1355,7 @@ int run_phi(hpf_handle *h, Side &own, Side &oth, hipEvent_t after_kernel)
   if (a.nseg) {
     const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own.chunks != nullptr) / 64 : 4;      // waves per workgroup
     const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
-    const PhiLaunch pl = {blocks, wpb * 64, st, h->phi_waves, h->phi_own_lds, h->phi_x2, h->phi_lds_pad};
+    const PhiLaunch pl = {blocks, wpb * 64, st};
     const bool ok = rows_in_pieces(h) ? launch_phi_packed(h->wl, h->phiG, h->phiR, side, a, pl)
                                       : launch_phi(h->w32, h->phiG, h->phiR, h->phiV, side, a, blocks, st);
     if (!ok) { h->err = "no phi kernel for this configuration"; return HPF_ERR_UNSUPPORTED; }
@@ -1903,10 +1874,6 @@ int hpf_create(const hpf_config *cfg, hpf_handle **out)
   if (const char *e = knob("HPF_TILE_SHARE")) { int v = atoi(e); if (v >= 0 && v <= 100) h->tile_min_share = v / 100.0; }
   if (const char *e = knob("HPF_PHI_BLOCKS")) { int v = atoi(e); if (v >= 1) h->phi_blocks = (uint32_t)v; }
   if (const char *e = knob("HPF_PHI_WG")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) h->phi_wg = (uint32_t)v; }
-  if (const char *e = knob("HPF_PHI_WAVES")) { int v = atoi(e); if (v == 3 || v == 4) h->phi_waves = v; }
-  if (const char *e = knob("HPF_PHI_OWN_LDS")) h->phi_own_lds = atoi(e) != 0;
-  if (const char *e = knob("HPF_PHI_X2")) h->phi_x2 = atoi(e) != 0;
-  if (const char *e = knob("HPF_PHI_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 160 * 1024) h->phi_lds_pad = (uint32_t)v; }
 
   const uint32_t n = cfg->n_users, m = cfg->n_items, ld = h->ld;
   h->u.rows = n; h->it.rows = m;
@@ -2918,11 +2885,6 @@ int hpf_get_work_info(hpf_handle *h, hpf_work_info *out)
   out->start_sums_pending = (h->jacobi && h->cfg.n_ranks > 1 && (h->sums_dirty || !h->start_sums_done || h->tail_partial)) ? 1u : 0u;
   out->graph_replay = (h->cfg.n_ranks == 1 && !h->comm) ? ((h->have_csr && want_graph(h)) ? 1u : 0u) : (h->have_csr && split_graph_on(h) ? 2u : 0u);
   out->tile_chunk_user = h->u.chunks ? h->u.chunk_segs : 0; out->tile_chunk_item = h->it.chunks ? h->it.chunk_segs : 0;
-  {
-    const bool six = h->wl == WL_P59 && h->phiR == 6;                 // the shapes the other builds exist for (launch_phipk_t)
-    const bool x2 = six && h->phi_x2 && h->phiG >= 8;
-    out->phi_build = six ? (uint32_t)(x2 ? 2 : h->phi_waves) | (h->phi_own_lds ? 16u : 0u) | (x2 ? 32u : 0u) : 3u;
-  }
   return HPF_OK;
 }
 
@@ -2945,7 +2907,7 @@ int hpf_gather_only(hpf_handle *h, int side, int reps, float *ms_out)
   if ((rc = dalloc(h, &sink, 1))) return rc;
   const uint32_t wpb = rows_in_pieces(h) ? h->wg_of(own.chunks != nullptr) / 64 : 4;        // the pass's own workgroups (run_phi)
   const uint32_t blocks = own.chunks ? own.nchunk_blocks : std::min<uint32_t>((a.nseg + wpb - 1) / wpb, h->phi_blocks * (4 / wpb));
-  const PhiLaunch pl = {blocks, wpb * 64, h->stream, h->phi_waves, h->phi_own_lds, h->wl == WL_P59 ? h->phi_x2 : 0, 0u};
+  const PhiLaunch pl = {blocks, wpb * 64, h->stream};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipError_t e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);

@@ -338,7 +338,6 @@ enum { WL_PLAIN = 0, WL_F48 = 2, WL_P59 = 3, WL_F64 = 4 };      // layout codes 
 template <int L> struct codec_f64 {
   static constexpr int E = 2 * L;
   static constexpr bool fixed_ld = false;
-  static constexpr __device__ int col(int e, int G) { return e * G; }   // column of element slot e in lane 0 of a G-lane group
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
   {
     return __hiloint2double((int)d[2 * e + 1], (int)d[2 * e]);
@@ -347,7 +346,6 @@ template <int L> struct codec_f64 {
 
 template <int L> struct codec_f48 {
   static constexpr bool fixed_ld = true;
-  static constexpr __device__ int col(int e, int G) { return e * G; }
   static constexpr int E = (8 * L) / 3;                   // 2 5 8 10 13 16 18 21
   static_assert(E + (E + 1) / 2 <= 4 * L, "lane dwords overflow");
   static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
@@ -359,7 +357,6 @@ template <int L> struct codec_f48 {
 
 template <int L> struct codec_p59 {
   static constexpr bool fixed_ld = true;
-  static constexpr __device__ int col(int e, int G) { return e * G; }
   static constexpr int E = (128 * L) / 59;                // 2 4 6 8 10 13 15 17
   static constexpr int S = (27 * E + 31) / 32;            // dwords of the field stream
   static_assert(E + S <= 4 * L, "lane dwords overflow");
@@ -391,33 +388,6 @@ template <int L> struct codec_p59 {
     uint32_t hi;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(f), "s"(0x7ffffffu), "v"(0x38000000u));
     return __hiloint2double((int)hi, (int)d[pos(e)]);
-  }
-};
-
-// p59 rows read by HALF as many lanes (round 6).  A row laid out for GV lanes of L1 pieces is, byte for byte, a row of
-// GV/2 lanes of 2 L1 pieces: piece t of virtual lane v = h GV/2 + g sits at byte ((2t + h) GV/2 + g) 16 -- piece 2t + h of
-// physical lane g.  A physical lane thus holds the dword streams of its two virtual lanes h = 0, 1 interleaved piece by
-// piece and decodes 2 E1 elements: slot e = h E1 + e1 is column e1 GV + h GV/2 + g.  Nothing about the stored rows, the
-// sweep or S changes; a batch holds twice the nonzeros and the group sum, the reciprocal and the addresses of a nonzero are
-// paid by half the lanes (K = 200: 8 lanes x 12 pieces over rows laid out (16, 6)).  L = pieces per PHYSICAL lane.
-template <int L> struct codec_p59x2 {
-  static_assert(L % 2 == 0, "two virtual lanes per physical lane");
-  using C1 = codec_p59<L / 2>;
-  static constexpr bool fixed_ld = true;
-  static constexpr int E1 = C1::E, E = 2 * E1;
-  static constexpr __device__ int col(int e, int G) { return (e % E1) * 2 * G + (e / E1) * G; }
-  static __device__ __forceinline__ double get(const uint32_t (&d)[4 * L], int e)
-  {
-    const int h = e / E1, e1 = e % E1;
-    const int o = 27 * e1, i = E1 + o / 32, sh = o % 32;
-    auto at = [&](int k) -> uint32_t { const int q = C1::pos(k); return d[4 * ((q / 4) * 2 + h) + q % 4]; };
-    uint32_t f;
-    if (sh == 0) f = at(i);
-    else if (sh + 27 <= 32) f = at(i) >> sh;
-    else f = __builtin_amdgcn_alignbit(at(i + 1), at(i), sh);
-    uint32_t hi;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(f), "s"(0x7ffffffu), "v"(0x38000000u));
-    return __hiloint2double((int)hi, (int)at(e1));
   }
 };
 
@@ -489,25 +459,16 @@ __device__ __forceinline__ void f64_put(void *W, size_t row, const PackedRow &pk
   d[((((e >> 1) << pk.lgG) + g) << 1) + (e & 1u)] = w;
 }
 
-// OWN_LDS: the owner's factors are read from LDS (own_l + e * G: this lane's column of element slot e) instead of from
-// E register pairs (phi_segments)
-typedef __attribute__((address_space(3))) double lds_double;      // a pointer that stays an LDS pointer (ds_read / ds_write) through inline asm
-template <class OthC, int E, int G, int LT, bool OWN_LDS>
-__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[OWN_LDS ? 1 : E], const lds_double *own_l,
+template <class OthC, int E, int G, int LT>
+__device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[E],
                                                  double (&acc)[E], float yf, bool &underflow)
 {
   double xv[E];
 #pragma unroll
   for (int e = E - 1; e >= 0; --e) xv[e] = OthC::get(x, e);     // last to first: codec_p59::pos
-  // (the empty asm hides from the compiler that the address is the same in every batch: left visible, the loads are hoisted
-  // out of the batch loop and the factors are back in registers -- or in scratch)
-  if (OWN_LDS) asm volatile("" : "+v"(own_l));
   double s[2] = {0.0, 0.0};
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const double o = OWN_LDS ? own_l[e * G] : own[OWN_LDS ? 0 : e];
-    s[e & 1] = (e < 2) ? o * xv[e] : fma(o, xv[e], s[e & 1]);
-  }
+  for (int e = 0; e < E; ++e) s[e & 1] = (e < 2) ? own[e] * xv[e] : fma(own[e], xv[e], s[e & 1]);
   const double ssum = group_sum<G>((E > 1) ? s[0] + s[1] : s[0]);
   const double yy = (double)yf;
   const bool ok = ssum > 0.0;
@@ -521,11 +482,9 @@ __device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], co
 // lane), the gathered rows in OthC's (LT pieces).  E = OwnC::E element slots are worked on (OthC::E >= E; the
 // library only instantiates OwnC = OthC -- the two-layout form is what the fp64-shadow experiment of round 4
 // ran on, profiles/r04/experiments.md 1).  W_own / W_oth already point at this lane's first piece.
-// OWN_LDS (round 6): the owner's decoded factors live in LDS -- own_l, G * E doubles of this wave, element slot e of lane
-// g at e * G + g -- instead of in E register pairs: the registers that frees are what a fourth wave per SIMD needs.
-template <class OwnC, class OthC, int G, int LO, int LT, bool OWN_LDS = false>
+template <class OwnC, class OthC, int G, int LO, int LT>
 __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &sr, const unsigned char *W_own,
-                                             const unsigned char *W_oth, int lane, bool &underflow, lds_double *own_l = nullptr)
+                                             const unsigned char *W_oth, int lane, bool &underflow)
 {
   constexpr int NG = 64 / G;
   constexpr int E = OwnC::E;
@@ -596,42 +555,29 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       cur_i = nxt_i; cur_y = nxt_y;
       fetch_after(b / G);
     };
-    double own[OWN_LDS ? 1 : E], acc[E];
+    double own[E], acc[E];
     {
       uint32_t r[4 * LO];
       load_own(r, W_own + (size_t)sg.row * ROWO);
       gather(xa, ya, 0);          // unconditional (a conditional gather costs copies and waits): past the
       gather(xb, yb, 1);          // segment's end the index reads 0 -- row 0, loaded and never used
       fetch_after(0);
-      if constexpr (OWN_LDS) {
-        // the previous segment's reads of own_l are behind us in program order and the LDS serves a wave's instructions in
-        // order; the barriers only keep the compiler from moving the accesses of other lanes' words across each other
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int e = E - 1; e >= 0; --e) { const double o = OwnC::get(r, e); if (q == 0) own_l[e * G + g] = o; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = 0.0;
-      } else {
-#pragma unroll
-        for (int e = E - 1; e >= 0; --e) { own[OWN_LDS ? 0 : e] = OwnC::get(r, e); acc[e] = 0.0; }
-      }
+      for (int e = E - 1; e >= 0; --e) { own[e] = OwnC::get(r, e); acc[e] = 0.0; }
     }
-    const lds_double *own_g = OWN_LDS ? own_l + g : nullptr;
     if (len > 0) {
       // same schedule as phi_pass_kernel: two register sets, peeled tail
       uint32_t bb = 0;
       for (; bb + 3 < nb; bb += 2) {
-        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
         __builtin_amdgcn_sched_barrier(0);
         if (((bb + 2) % G) == 0) next_chunk(bb + 2);
         gather(xa, ya, bb + 2);
-        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xb, own, own_g, acc, yb, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
         __builtin_amdgcn_sched_barrier(0);
         gather(xb, yb, bb + 3);
       }
-      phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
+      phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
       if (bb + 1 < nb) {
         const bool third = bb + 2 < nb;
         __builtin_amdgcn_sched_barrier(0);
@@ -639,8 +585,8 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
           if (((bb + 2) % G) == 0) next_chunk(bb + 2);
           gather(xa, ya, bb + 2);
         }
-        phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xb, own, own_g, acc, yb, underflow);
-        if (third) phi_batch_packed<OthC, E, G, LT, OWN_LDS>(xa, own, own_g, acc, ya, underflow);
+        phi_batch_packed<OthC, E, G, LT>(xb, own, acc, yb, underflow);
+        if (third) phi_batch_packed<OthC, E, G, LT>(xa, own, acc, ya, underflow);
       }
     }
     double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + g;
@@ -651,26 +597,25 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       if (G <= 16) r += __shfl_xor(r, 16, 64);
       if (G <= 8)  r += __shfl_xor(r, 8, 64);
       if (G <= 4)  r += __shfl_xor(r, 4, 64);
-      const double o = OWN_LDS ? own_g[e * G] : own[OWN_LDS ? 0 : e];
-      if (q == 0 && (OwnC::fixed_ld || (uint32_t)(OwnC::col(e, G) + g) < LD)) dst[(size_t)OwnC::col(e, G)] = o * r;
+      if (q == 0 && (OwnC::fixed_ld || (uint32_t)(e * G + g) < LD)) dst[(size_t)e * G] = own[e] * r;
     }
   }
 }
 
-// WAVES: waves per SIMD the register allocation is held to (3: 168 VGPRs, 4: 128, 2: 256); OWN: the owner's factors in LDS
-// (phi_segments).  SIDE stays the last template argument: the profiles tell the passes apart by it.
-template <template <int> class CodecT, int G, int L, int WAVES, int OWN, int SIDE>
-__global__ __launch_bounds__(256, WAVES) void phi_pass_packed_kernel(PhiArgs a)
+// Three waves per SIMD (168 VGPRs).  Round 6 built and measured the other ways of spending the registers -- a fourth wave
+// with the owner's factors in LDS, rows read by half their lanes (twice the nonzeros per batch, two waves) -- and an LDS pad
+// that takes waves away: 3 -> 2 waves cost 7-18 %, every build that spills inside the batch loop loses far more (a scratch
+// reload waits behind every gather in flight), and none reaches the one below (profiles/r06/experiments.md 2, 3;
+// pass_builds_prototype.diff keeps the code).
+template <template <int> class CodecT, int G, int L, int SIDE>
+__global__ __launch_bounds__(256, 3) void phi_pass_packed_kernel(PhiArgs a)
 {
-  constexpr int E = CodecT<L>::E;
-  __shared__ double own_sh[OWN ? 4 * G * E : 1];      // a row of decoded factors per wave of the workgroup
   if (phi_pass_skips(a, SIDE)) return;
   const int lane = threadIdx.x & 63;
   const SegRange sr = seg_range(a);
   bool underflow = false;
-  phi_segments<CodecT<L>, CodecT<L>, G, L, L, OWN != 0>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
-                                                        (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, underflow,
-                                                        (lds_double *)own_sh + (OWN ? (threadIdx.x >> 6) * (G * E) : 0));
+  phi_segments<CodecT<L>, CodecT<L>, G, L, L>(a, sr, (const unsigned char *)a.W_own + (size_t)(lane % G) * 16,
+                                              (const unsigned char *)a.W_oth + (size_t)(lane % G) * 16, lane, underflow);
   if (__any(underflow) && lane == 0) atomicOr(a.flags, 1u);
 }
 

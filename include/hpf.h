@@ -367,8 +367,7 @@ typedef struct {
   /* ABI v8 */
   uint32_t tile_chunk_user;          /* segments per workgroup of that side's tiled pass (0: row-major): two per wave     */
   uint32_t tile_chunk_item;          /* unless the list is too long for one launch of such chunks                         */
-  uint32_t phi_build;                /* build of the packed pass kernels in use: bits 0-3 waves per SIMD the registers are */
-                                     /* held to, bit 4 the owner's factors in LDS, bit 5 rows read by half their lanes     */
+  uint32_t reserved0;
 } hpf_work_info;
 int  hpf_get_work_info(hpf_handle *h, hpf_work_info *out);
 

@@ -37,7 +37,7 @@ def test_config_struct_layout_matches_header():
     # 12 x 4-byte fields, one pointer, two doubles, novb + reserved (ABI v4)
     assert C.sizeof(capi.HpfConfig) == 12 * 4 + 8 + 16 + 8
     assert C.sizeof(capi.HpfTiming) == 36            # 8 floats + the iteration counter
-    assert C.sizeof(capi.HpfWorkInfo) == 8 + 24 * 4 + 2 * 8      # ABI v5: + tile rows and the heavy bars of both sides; v7: + start_sums_pending; v8: + tile_chunk_user / _item, phi_build
+    assert C.sizeof(capi.HpfWorkInfo) == 8 + 24 * 4 + 2 * 8      # ABI v5: + tile rows and the heavy bars of both sides; v7: + start_sums_pending; v8: + tile_chunk_user / _item, reserved0
 
 
 def test_no_oracle_on_the_product_path():

@@ -746,41 +746,6 @@ def test_every_packed_kernel_shape_matches_the_oracle(orc, monkeypatch, K, ws):
         assert e < RTOL, (wi["phi_G"], wi["phi_R"], wi["sweep_G"], wi["sweep_R"], w, e)
 
 
-@pytest.mark.parametrize("waves,own_lds,x2", [(3, 0, 0), (4, 0, 0), (4, 1, 0), (3, 1, 0), (3, 0, 1), (3, 1, 1)],
-                         ids=["w3", "w4", "w4_lds", "w3_lds", "x2", "x2_lds"])
-@pytest.mark.parametrize("K,bias", [(50, False), (100, False), (100, True), (200, True)])
-def test_every_build_of_the_packed_pass_matches_the_oracle(orc, monkeypatch, K, bias, waves, own_lds, x2):
-    """Round 6: the builds of the packed pass for the shapes of six pieces per lane (K = 50, 100, 200) -- registers held to
-    three or four waves per SIMD, the owner's factors in registers or in LDS, rows read by all their lanes or by half of them
-    (codec_p59x2: a batch of twice the nonzeros) -- over long rows, empty rows and rows cut into several segments, against
-    the oracle; a build that keeps the lanes per nonzero sums in the same order as the default one: the same bits."""
-    from hgaprec_amd.capi import Hpf
-    n, m = 260, 170
-    kw = dict(prob_kw=dict(heavy_user=True, heavy_item=True, singles=True))
-    monkeypatch.setenv("HPF_EXPERIMENTAL", "1")
-    monkeypatch.setenv("HPF_PHI_WAVES", str(waves))
-    monkeypatch.setenv("HPF_PHI_OWN_LDS", str(own_lds))
-    monkeypatch.setenv("HPF_PHI_X2", str(x2))
-    monkeypatch.setenv("HPF_SEG_MAX", "64")            # rows of several segments, partial slots
-    M, D = _run_pair(orc, n, m, K, 9000, True, bias, False, 3, seed=3 + K, **kw)
-    wi = D.work_info()
-    halves = x2 and wi["phi_G"] >= 8
-    assert wi["w_layout"] == 3 and wi["phi_R"] == 6
-    assert wi["phi_build"] == ((2 if halves else waves) | (16 if own_lds else 0) | (32 if halves else 0)), wi
-    M.iterate(3); D.iterate(3)
-    for w in compare_states(True, bias):
-        e = rel_err(D.get_state(w), M.state(w))
-        assert e < RTOL, (wi["phi_G"], wi["phi_build"], w, e)
-    if not halves:
-        monkeypatch.delenv("HPF_PHI_WAVES"); monkeypatch.delenv("HPF_PHI_OWN_LDS"); monkeypatch.delenv("HPF_PHI_X2")
-        Mb, Db = _run_pair(orc, n, m, K, 9000, True, bias, False, 3, seed=3 + K, **kw)     # same lists (HPF_SEG_MAX), the default build
-        Db.iterate(3)
-        for w in compare_states(True, bias):
-            assert np.array_equal(D.get_state(w), Db.get_state(w)), (wi["phi_build"], w)
-        Db.close()
-    D.close()
-
-
 @pytest.mark.parametrize("K,bias", [(100, False), (50, True), (202, False)])
 def test_packed_rows_are_lossless_against_plain_rows(orc, monkeypatch, K, bias):
     """The 59-bit packing drops only bits that carry nothing: a packed run and a run with the same

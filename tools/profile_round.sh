@@ -41,6 +41,11 @@ if [ -x /opt/rocm/bin/hipcc ]; then
 fi
 tools/sweep_probe > $OUT/sweep_probe.json 2> $OUT/sweep_probe.log
 tools/gather_ceiling > $OUT/gather_ceiling.json 2> $OUT/gather_ceiling.log
+# 7a. (round 6) the same gathers with a share served by the XCD's L2 and the rest over the fabric: the ceiling of a tiled pass
+if [ -x /opt/rocm/bin/hipcc ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/mixed_gather tools/mixed_gather.hip > /dev/null 2>&1
+fi
+tools/mixed_gather > $OUT/mixed_gather.json 2> $OUT/mixed_gather.log
 # 7b. the sweep at the C3-shard shape: blocks x rows held ahead; sweep_probe_pipe2 = the same source built with -DHPF_SWEEP_PIPE=2
 if [ -x /opt/rocm/bin/hipcc ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHPF_SWEEP_PIPE=2 -o tools/sweep_probe_pipe2 tools/sweep_probe.hip > /dev/null 2>&1
@@ -51,7 +56,7 @@ for b in 1024 2048 4096 8192; do
   [ -x tools/sweep_probe_pipe2 ] && tools/sweep_probe_pipe2 1250000 $b >> $OUT/sweep_probe_c3shard.jsonl 2>> $OUT/sweep_probe.log
 done
 # 8. report-step operations at C2 (held-out LL, ELBO, ranking evaluation)
-python tools/bench_report_step.py C2 > $OUT/report_step_c2.json 2> $OUT/report_step_c2.log
+python tools/bench_report_step.py C2 1250000 > $OUT/report_step_c2.json 2> $OUT/report_step_c2.log
 # 9. counters for the OTHER shapes: C4 whole, and what one of 8 GPUs holds of C3 and of C5 (the first
 #    1/8 of the users of the real matrix, all items) -- the same passes as step 2, per shape, under $OUT/cfg_<label>/
 cfgprof() {
