@@ -735,6 +735,9 @@ __device__ __forceinline__ ColQuad combine_columns(const double *partial, uint32
 #pragma unroll
     for (int j = 0; j < 16; ++j) { s.a0 += v0[j].x; s.a1 += v0[j].y; s.b0 += v1[j].x; s.b1 += v1[j].y; }
   }
+  // (the last < 16 slots one by one.  Round 6 tried them as one more round of sixteen clamped loads with the adds past the end
+  // skipped: most rows of this list have two or three slots, and sixteen loads where three would do cost more than the chain
+  // of a 176-slot row's last twelve saves -- C5 shard combines 0.57 + 0.51 -> 1.17 + 0.80 ms, C3 shard 0.26 -> 0.39; reverted)
   for (; q < nslots; ++q) { const double2 u = p0[(size_t)q * st], w = p1[(size_t)q * st]; s.a0 += u.x; s.a1 += u.y; s.b0 += w.x; s.b1 += w.y; }
   return s;
 }
