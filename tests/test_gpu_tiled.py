@@ -171,6 +171,7 @@ def test_automatic_policy_tiles_a_skewed_side_only(orc):
     copy_state(M, D, True, False)
     wi = D.work_info()
     assert wi["tiles_item"] >= 8 and wi["tiles_user"] == 0, wi
+    assert wi["tile_chunk_item"] == 2 and wi["tile_chunk_user"] == 0, wi       # one wave per workgroup, two segments per chunk (ABI v8 says so)
     M.iterate(2); D.iterate(2)
     for w in compare_states(True, False):
         assert _err(w, D.get_state(w), M.state(w)) < RTOL, w
@@ -179,7 +180,8 @@ def test_automatic_policy_tiles_a_skewed_side_only(orc):
     D.close()
 
 
-def test_tiled_list_longer_than_a_launch_holds(tile_env):
+@pytest.mark.parametrize("K", [5, 100])
+def test_tiled_list_longer_than_a_launch_holds(tile_env, K):
     """A launch holds fewer than 2^32 work-items, i.e. 2^20 workgroups of 256: with 1 KiB tiles this
     matrix is cut into ~10^7 segments -- more than 2^20 chunks of eight -- so the chunks must grow
     instead of the grid.  (A grid past the limit is silently cut short: found with whole-suite runs
@@ -187,13 +189,20 @@ def test_tiled_list_longer_than_a_launch_holds(tile_env):
     import torch
     from tests.test_gpu_fullsize import _device_model, _row_mass
     from hgaprec_amd import synth
-    tile_env(HPF_TILE=1, HPF_TILE_BYTES=1024)
-    n, m, nnz, K = 200_000, 20_000, 20_000_000, 5
+    tile_env(HPF_TILE=1, HPF_TILE_BYTES=1024 if K == 5 else 4096)       # K = 100: 768-byte rows, five to a tile (at most 65 534 tiles)
+    n, m, nnz = 200_000, 20_000, 20_000_000
     dev = torch.device("cuda", 0)
     rowptr, col, val = synth.generate_device(n, m, nnz, 0.4, 0.7, seed=5, device=dev, binary=True)
     D = _device_model(dict(m=m, K=K, binary=True), n, rowptr, col, None, 0, n)
     wi = D.work_info()
     assert wi["tiles_user"] > 100 and wi["tiles_item"] > 1000 and wi["item_segments"] > 8 * (1 << 20), wi
+    if K == 5:
+        assert wi["w_layout"] == 0 and wi["tile_chunk_item"] > 8, wi          # four-wave workgroups: 2^20 of them, chunks of eight grew
+    else:
+        # packed rows: one-wave workgroups, of which a launch holds 2^22 (capped at 2^20 like the four-wave groups,
+        # a list this long got chunks of 32 and more instead of two; the cap now scales with the workgroup size)
+        assert wi["w_layout"] == 3 and 2 < wi["tile_chunk_item"] <= 16, wi
+        assert wi["item_segments"] / wi["tile_chunk_item"] <= (1 << 22), wi
     D.iterate(2)
     ts, bs = D.get_state_device("THETA_SHAPE", dev), D.get_state_device("BETA_SHAPE", dev)
     deg_u = _row_mass(rowptr, None)

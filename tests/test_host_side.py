@@ -417,6 +417,29 @@ print(rc, full, os.path.getsize(path), os.path.exists(path + ".writing"))
     assert not (tmp_path / "m.tsv.writing").exists() and len((tmp_path / "m.tsv").read_text().splitlines()) == 5
 
 
+def test_a_target_that_cannot_be_opened_gets_no_marker(tmp_path):
+    """the marker used to be created before the open of the file itself, so a target that could not be opened -- an
+    old file nobody had touched, still whole -- got a "<file>.writing" beside it, which says "not whole"; and a target that
+    is no regular file (/dev/null) got one as well.  Now the marker follows a successful open, beside regular files only."""
+    import os
+    d = tmp_path / "ro"
+    d.mkdir()
+    good = d / "old.tsv"
+    assert hostlib.save_matrix(good, np.ones((4, 3)), None) == 0
+    before = good.read_text()
+    # a directory in place of the target: open(O_WRONLY) fails whoever runs the test (root ignores file modes)
+    (d / "isdir.tsv").mkdir()
+    assert hostlib.save_matrix(d / "isdir.tsv", np.ones((4, 3)), None) != 0
+    assert not (d / "isdir.tsv.writing").exists()
+    # a path under a missing directory: the target cannot be created
+    assert hostlib.save_matrix(d / "missing" / "x.tsv", np.ones((2, 2)), None) != 0
+    assert not (d / "missing").exists()
+    assert good.read_text() == before and not (d / "old.tsv.writing").exists()
+    # not a regular file: written, never marked
+    assert hostlib.save_vector("/dev/null", np.ones(5), None) == 0
+    assert not os.path.exists("/dev/null.writing")
+
+
 def test_read_threads_override_is_clamped(tmp_path, monkeypatch):
     """HGAPREC_READ_THREADS = -3 or garbage used to become 64 threads through an unsigned cast; and text too
     large for a quarter of the free memory (HGAPREC_READ_PARALLEL_MAX stands in) goes to the token-by-token reader --
