@@ -190,8 +190,12 @@ def test_vb_bias_novb_across_two_ranks(orc):
     with pytest.raises(HpfError, match="hpf_start_sums"):
         shards[0].iterate_local()
     ld = shards[0].work_info()["ld"]
+    assert all(D.work_info()["start_sums_pending"] == 1 for D in shards)
     for D in shards:
         D.start_sums()
+    # ABI v8: the field keeps reading 1 while the tail holds this rank's PART -- a caller may look before or after
+    # hpf_start_sums -- until the first pass of the next iteration
+    assert all(D.work_info()["start_sums_pending"] == 1 for D in shards)
     bufs = [D.exchange_read() for D in shards]
     tail = bufs[0][-ld:] + bufs[1][-ld:]
     assert np.allclose(tail[:K], init["THETA_E"].sum(0), rtol=1e-13)
@@ -202,6 +206,7 @@ def test_vb_bias_novb_across_two_ranks(orc):
         M.iterate(1)
         for D in shards:
             D.iterate_local()
+            assert D.work_info()["start_sums_pending"] == 0
         bufs = [D.exchange_read() for D in shards]
         tot = bufs[0] + bufs[1]
         for D in shards:
