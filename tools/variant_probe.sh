@@ -2,6 +2,8 @@
 # EXPERIMENT (round 6): builds of the packed phi pass on the four shapes -- last round's library beside this one's, then
 # waves per SIMD (HPF_PHI_WAVES), the owner's factors in LDS (HPF_PHI_OWN_LDS) and rows read by half their lanes
 # (HPF_PHI_X2); ms per kernel from bench.py --lean.  Usage: bash tools/variant_probe.sh [tag] [reps]
+# FOR THE RECORD (profiles/r06/experiments.md 2): the knobs exist only with profiles/r06/pass_builds_prototype.diff applied, and
+# hgaprec_amd/libhpf_hip_r05.so is round 5's hpf_capi.hip (git show f06a9f0:...) built beside this one.
 OUT=gpurun_out/${1:-r06}; mkdir -p $OUT
 REPS=${2:-2}
 run() { # label, env..., -- args
