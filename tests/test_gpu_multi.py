@@ -390,6 +390,11 @@ def test_eight_ranks_through_the_launcher_on_one_gpu():
         k = max(r.stderr.find("Traceback"), 0)
         first = r.stderr[max(0, k - 1500): k + 3000] + "\n...\n" + r.stderr[-1500:]
         print("first launch failed, trying once more:\n" + first, file=sys.stderr)
+        try:                                                           # kept for a post-mortem even when the second try passes
+            (ROOT / "gpurun_out").mkdir(exist_ok=True)
+            (ROOT / "gpurun_out" / "eight_rank_first_failure.log").write_text(r.stderr)
+        except OSError:
+            pass
         r = launch()
         if r.returncode != 0:
             raise AssertionError(first)
