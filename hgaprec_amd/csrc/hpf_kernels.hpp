@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // Build-time switches (A/B builds of tools/ and profiles/ only; the library ships the defaults)
 #ifndef HPF_P59_PAIRED
@@ -728,16 +729,23 @@ __device__ __forceinline__ ColQuad combine_columns(const double *partial, uint32
   const size_t st = ld / 2;                        // row stride in double2
   ColQuad s = {0.0, 0.0, 0.0, 0.0};
   uint32_t q = 0;
-  for (; q + 16 <= nslots; q += 16) {
-    double2 v0[16], v1[16];
+  // N slots' loads in flight, then their adds in slot order
+  auto round = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    double2 v0[N], v1[N];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { v0[j] = p0[(size_t)(q + j) * st]; v1[j] = p1[(size_t)(q + j) * st]; }
+    for (int j = 0; j < N; ++j) { v0[j] = p0[(size_t)(q + j) * st]; v1[j] = p1[(size_t)(q + j) * st]; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { s.a0 += v0[j].x; s.a1 += v0[j].y; s.b0 += v1[j].x; s.b1 += v1[j].y; }
-  }
-  // (the last < 16 slots one by one.  Round 6 tried them as one more round of sixteen clamped loads with the adds past the end
-  // skipped: most rows of this list have two or three slots, and sixteen loads where three would do cost more than the chain
-  // of a 176-slot row's last twelve saves -- C5 shard combines 0.57 + 0.51 -> 1.17 + 0.80 ms, C3 shard 0.26 -> 0.39; reverted)
+    for (int j = 0; j < N; ++j) { s.a0 += v0[j].x; s.a1 += v0[j].y; s.b0 += v1[j].x; s.b1 += v1[j].y; }
+    q += N;
+  };
+  while (q + 16 <= nslots) round(std::integral_constant<int, 16>());
+  // the last < 16 slots: a round of eight and one of four where they fit, only the last < 4 one by one (round 6: walked one
+  // by one -- load, wait, add -- the last twelve of a 44-slot quarter were a chain of twelve round trips.  The same loads, the
+  // same adds in the same order: the same bits.  A first attempt padded the tail to sixteen CLAMPED loads instead: the light
+  // rows of two or three slots then paid for sixteen, and everything got slower -- profiles/r06/experiments.md 9)
+  if (q + 8 <= nslots) round(std::integral_constant<int, 8>());
+  if (q + 4 <= nslots) round(std::integral_constant<int, 4>());
   for (; q < nslots; ++q) { const double2 u = p0[(size_t)q * st], w = p1[(size_t)q * st]; s.a0 += u.x; s.a1 += u.y; s.b0 += w.x; s.b1 += w.y; }
   return s;
 }
