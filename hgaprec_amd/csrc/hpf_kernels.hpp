@@ -20,6 +20,9 @@
 #include <type_traits>
 
 // Build-time switches (A/B builds of tools/ and profiles/ only; the library ships the defaults)
+#ifndef HPF_REDUCE_SCATTER
+#define HPF_REDUCE_SCATTER 1   // end of a segment in the packed passes: 1 = the groups' accumulators reduced halving the element list
+#endif                         // per level (round 6), 0 = every element on every lane at every level (rounds 1-5); the same bits
 #ifndef HPF_P59_PAIRED
 #define HPF_P59_PAIRED 1       // order of a p59 lane's dwords: 1 = (low word, stream dword) pairs (round 6), 0 = round 5's
 #endif
@@ -460,6 +463,52 @@ __device__ __forceinline__ void f64_put(void *W, size_t row, const PackedRow &pk
   d[((((e >> 1) << pk.lgG) + g) << 1) + (e & 1u)] = w;
 }
 
+// ---- reduce-scatter of a wave's 64 / G group accumulators (phi_segments) --------------------------------------------
+// element slots a lane holds after the levels at lane distances D, D/2, ..., G
+template <int G, int N, int D = 32> struct scatter_len_at { static constexpr int value = D >= G ? scatter_len_at<G, (N + 1) / 2, D / 2>::value : N; };
+template <int G, int N> struct scatter_len_at<G, N, 0> { static constexpr int value = N; };
+template <int G, int E> struct scatter_len { static constexpr int value = scatter_len_at<G, E, 32>::value; };
+
+// one level at lane distance D over the first N slots of v / w (w: the owner's factors, selected alongside); o, n: the run
+// of element slots this lane holds -- [o, o + n) -- before and after
+template <int G, int E, int D, int N = E>
+__device__ __forceinline__ void reduce_scatter(double (&v)[E], double (&w)[E], int lane, uint32_t &o, uint32_t &n)
+{
+  if constexpr (D >= G && D >= 1) {
+    constexpr int NA = (N + 1) / 2;                       // the half a lane with bit D clear keeps
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool hasB = NA + j < N;
+      const double A = v[j], B = hasB ? v[NA + j] : 0.0;
+      if constexpr (D == 32 || D == 16) {
+        // gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd 16-lane rows) of one register with
+        // the lower half (the even rows) of another: with A and B as the two registers, afterwards the FIRST holds, on the
+        // lanes that keep A, their own A and, on the lanes that keep B, the partner's B -- and the second the other two.
+        // Their sum is mine + the partner's on every lane: no select, no LDS crossbar.
+        const uint32_t alo = (uint32_t)__double2loint(A), ahi = (uint32_t)__double2hiint(A);
+        const uint32_t blo = (uint32_t)__double2loint(B), bhi = (uint32_t)__double2hiint(B);
+        double x, y;
+        if constexpr (D == 32) {
+          const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+          x = __hiloint2double((int)hi[0], (int)lo[0]); y = __hiloint2double((int)hi[1], (int)lo[1]);
+        } else {
+          const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+          x = __hiloint2double((int)hi[0], (int)lo[0]); y = __hiloint2double((int)hi[1], (int)lo[1]);
+        }
+        v[j] = x + y;
+      } else {
+        const double mine = up ? B : A, send = up ? A : B;
+        v[j] = mine + (D == 8 ? dpp_mov<0x128>(send) /* row_ror:8 = lane ^ 8 inside a 16-lane row */ : __shfl_xor(send, D, 64));
+      }
+      if (hasB) w[j] = up ? w[NA + j] : w[j];
+    }
+    o += up ? (uint32_t)NA : 0u;
+    n = up ? (n > (uint32_t)NA ? n - (uint32_t)NA : 0u) : (n < (uint32_t)NA ? n : (uint32_t)NA);
+    reduce_scatter<G, E, D / 2, NA>(v, w, lane, o, n);
+  }
+}
+
 template <class OthC, int E, int G, int LT>
 __device__ __forceinline__ void phi_batch_packed(const uint32_t (&x)[4 * LT], const double (&own)[E],
                                                  double (&acc)[E], float yf, bool &underflow)
@@ -591,6 +640,24 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       }
     }
     double *dst = ((sg.pslot >= 0) ? a.partial + (size_t)sg.pslot * LD : a.S_own + (size_t)sg.row * LD) + g;
+#if HPF_REDUCE_SCATTER
+    // The 64 / G groups' accumulators, reduced HALVING the element list at every level instead of keeping every element on
+    // every lane: at lane distance d a lane whose bit d is clear keeps the first half of its list and hands the second half to
+    // its partner, and the other way round -- the same pairs are added as in the butterfly below (a + b on one lane is b + a
+    // on the other: the same bits), but a level moves half the elements of the one before: 13 -> 7 -> 4 -> 2 (-> 1) shuffles
+    // instead of 13 per level, and in the end lane (q, g) holds the totals of a contiguous run of element slots [o, o + n)
+    // of column lane g, which ALL lanes then store at once.  The owner's factors follow by selects (no shuffle).
+    {
+      uint32_t o = 0, n = E;
+      reduce_scatter<G, E, 32>(acc, own, lane, o, n);
+      constexpr int NF = scatter_len<G, E>::value;          // element slots a lane ends with, at most
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const uint32_t e = o + (uint32_t)j;
+        if ((uint32_t)j < n && (OwnC::fixed_ld || e * G + (uint32_t)g < LD)) dst[(size_t)e * G] = own[j] * acc[j];
+      }
+    }
+#else
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       double r = acc[e];
@@ -600,6 +667,7 @@ __device__ __forceinline__ void phi_segments(const PhiArgs &a, const SegRange &s
       if (G <= 4)  r += __shfl_xor(r, 4, 64);
       if (q == 0 && (OwnC::fixed_ld || (uint32_t)(e * G + g) < LD)) dst[(size_t)e * G] = own[e] * r;
     }
+#endif
   }
 }
 
